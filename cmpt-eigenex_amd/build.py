@@ -1,0 +1,81 @@
+"""Build recipe for the gfx950 libraries (hipcc, in-tree, no JIT cache).
+
+  libeigenex_hip.so   hand-written HIP kernels + the C ABI of include/eigenex_hip.h
+  libeigenex_solver.so  flat C view of the header-only C++ solver classes
+                        (cmpt-eigenex_amd/include/cmpt/eigen_ex/*.hpp) for ctypes users
+
+`python -m cmpt_eigenex_amd.build` or __graft_entry__.build() runs it; hipcc
+cross-compiles for gfx950 without a GPU.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+LIBDIR = os.path.join(PKG, "lib")
+CSRC = os.path.join(PKG, "csrc")
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+
+
+def _hipcc() -> str:
+    for cand in (os.path.join(ROCM, "bin", "hipcc"), shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the HIP extension cannot be built")
+
+
+def _newer(target: str, sources) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _all_headers():
+    out = []
+    for base in (CSRC, os.path.join(ROOT, "include"), os.path.join(PKG, "include")):
+        for d, _, fs in os.walk(base):
+            out += [os.path.join(d, f) for f in fs if f.endswith((".h", ".hpp"))]
+    return out
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    so = os.path.join(LIBDIR, "libeigenex_hip.so")
+    srcs = [os.path.join(CSRC, "kernels.hip"), os.path.join(CSRC, "library.hip")]
+    if force or _newer(so, srcs + _all_headers()):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", so, *srcs,
+               "-I", os.path.join(ROOT, "include"), "-L", os.path.join(ROCM, "lib"), "-lrccl",
+               "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-Wno-unused-value"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return so
+
+
+def build_solver(force: bool = False, verbose: bool = False) -> str:
+    so = os.path.join(LIBDIR, "libeigenex_solver.so")
+    src = os.path.join(CSRC, "solver_capi.cpp")
+    if not os.path.exists(src):
+        return ""
+    hip_so = build_hip(force=False, verbose=verbose)
+    if force or _newer(so, [src, hip_so] + _all_headers()):
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", so, src,
+               "-I", os.path.join(ROOT, "include"), "-I", os.path.join(PKG, "include"),
+               "-L", LIBDIR, "-leigenex_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return so
+
+
+def build_all(force: bool = False, verbose: bool = False):
+    return build_hip(force, verbose), build_solver(force, verbose)
+
+
+if __name__ == "__main__":
+    print(build_all(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,333 @@
+"""ctypes binding of include/eigenex_hip.h (the C ABI of libeigenex_hip.so).
+
+This is plumbing for tests/ and bench.py; the product's host side is the
+header-only C++ in cmpt-eigenex_amd/include/cmpt/eigen_ex/.  Nothing here
+computes: every function forwards to the HIP library and raises EigenexError
+when the library reports a failure (there is no CPU fallback).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libeigenex_hip.so")
+
+ORTHO_BATCHED = 0
+ORTHO_SEQUENTIAL = 1
+VEC_V = -1
+VEC_W = -2
+K_SPMV, K_DOTS, K_UPDATE, K_SMALL, K_COMM, K_RITZ = range(6)
+
+
+def VEC_COL(c: int) -> int:
+    return int(c)
+
+
+def VEC_ORTHO(q: int) -> int:
+    return -16 - int(q)
+
+
+class EigenexError(RuntimeError):
+    pass
+
+
+class State(C.Structure):
+    _fields_ = [("nvec", C.c_int32), ("iterations", C.c_int32), ("nalpha", C.c_int32), ("nbeta", C.c_int32),
+                ("stopped", C.c_int32), ("calls_true", C.c_int32), ("residue", C.c_double)]
+
+
+MATVEC_FN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p)
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_lp = C.POINTER(C.c_int64)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes): every symbol include/eigenex_hip.h declares
+SIGNATURES = {
+    "eigenex_version": (C.c_int, []),
+    "eigenex_last_error": (C.c_char_p, []),
+    "eigenex_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "eigenex_partition": (C.c_int, [C.c_int64, C.c_int, C.c_int, _lp, _lp]),
+    "eigenex_halo_plan": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.c_int64, _ip, _lp, _ip, _lp]),
+    "eigenex_rccl_unique_id": (C.c_int, [_vp]),
+    "eigenex_context_create": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
+    "eigenex_context_create_loopback": (C.c_int, [C.c_int, C.c_int, C.POINTER(_vp)]),
+    "eigenex_context_destroy": (C.c_int, [_vp]),
+    "eigenex_context_sync": (C.c_int, [_vp]),
+    "eigenex_context_info": (C.c_int, [_vp] + [C.POINTER(C.c_int)] * 4),
+    "eigenex_context_stream": (_vp, [_vp]),
+    "eigenex_profile_enable": (C.c_int, [_vp, C.c_int]),
+    "eigenex_profile_reset": (C.c_int, [_vp]),
+    "eigenex_profile_get": (C.c_int, [_vp, C.c_int, _lp, _dp, _dp]),
+    "eigenex_csr_upload": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int64, _ip, _ip, _dp, C.POINTER(_vp)]),
+    "eigenex_csr_laplacian3d": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp)]),
+    "eigenex_csr_destroy": (C.c_int, [_vp]),
+    "eigenex_csr_info": (C.c_int, [_vp, _lp, _lp, _lp, _lp]),
+    "eigenex_basis_create": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "eigenex_basis_destroy": (C.c_int, [_vp]),
+    "eigenex_basis_set_host_operator": (C.c_int, [_vp, MATVEC_FN, _vp]),
+    "eigenex_basis_configure": (C.c_int, [_vp, C.c_double, C.c_double, C.c_int64, C.c_int]),
+    "eigenex_basis_clear": (C.c_int, [_vp]),
+    "eigenex_vec_upload": (C.c_int, [_vp, C.c_int, _dp]),
+    "eigenex_vec_download": (C.c_int, [_vp, C.c_int, _dp]),
+    "eigenex_apply": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, _dp]),
+    "eigenex_dots": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
+    "eigenex_update": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp]),
+    "eigenex_axpy2": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int]),
+    "eigenex_scale": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double]),
+    "eigenex_lanczos_enqueue": (C.c_int, [_vp, C.c_int]),
+    "eigenex_arnoldi_enqueue": (C.c_int, [_vp, C.c_int]),
+    "eigenex_lanczos_state": (C.c_int, [_vp, C.POINTER(State), _dp, _dp]),
+    "eigenex_arnoldi_state": (C.c_int, [_vp, C.POINTER(State), _dp, C.c_int]),
+    "eigenex_ritz_vectors": (C.c_int, [_vp, C.c_int, C.c_int, _dp, C.c_int, _dp, C.c_int64]),
+}
+
+_LIB = None
+
+
+def lib():
+    """Load libeigenex_hip.so (built in-tree by cmpt_eigenex_amd.build).  Fails loudly if missing."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise EigenexError(
+                f"{LIB_PATH} is missing: build it with `python -m cmpt_eigenex_amd.build` "
+                "(there is no CPU fallback for the Krylov hot path)")
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def _chk(rc: int):
+    if rc != 0:
+        raise EigenexError(f"eigenex error {rc}: {lib().eigenex_last_error().decode(errors='replace')}")
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip)
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = lib().eigenex_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def partition(n_global: int, nshards: int, shard: int):
+    b, e = C.c_int64(), C.c_int64()
+    _chk(lib().eigenex_partition(n_global, nshards, shard, C.byref(b), C.byref(e)))
+    return b.value, e.value
+
+
+def halo_plan(n_global: int, nshards: int, shard: int, col_global: np.ndarray):
+    col = np.ascontiguousarray(col_global, np.int32)
+    nh = C.c_int64()
+    _chk(lib().eigenex_halo_plan(n_global, nshards, shard, col.size, _i(col), C.byref(nh), None, None))
+    cols = np.empty(nh.value, np.int32)
+    per = np.zeros(nshards, np.int64)
+    _chk(lib().eigenex_halo_plan(n_global, nshards, shard, col.size, _i(col), C.byref(nh), _i(cols),
+                                 per.ctypes.data_as(_lp)))
+    return cols, per
+
+
+def rccl_unique_id() -> bytes:
+    buf = C.create_string_buffer(128)
+    _chk(lib().eigenex_rccl_unique_id(buf))
+    return buf.raw
+
+
+class Context:
+    def __init__(self, device=0, rank=0, world_size=1, rccl_id: bytes | None = None, loopback_shards: int = 0):
+        self.h = _vp()
+        if loopback_shards:
+            _chk(lib().eigenex_context_create_loopback(device, loopback_shards, C.byref(self.h)))
+        else:
+            idbuf = C.create_string_buffer(rccl_id, 128) if rccl_id else None
+            _chk(lib().eigenex_context_create(device, rank, world_size, idbuf, C.byref(self.h)))
+
+    def info(self):
+        v = [C.c_int() for _ in range(4)]
+        _chk(lib().eigenex_context_info(self.h, *[C.byref(x) for x in v]))
+        return dict(zip(("rank", "world_size", "nshards_total", "nshards_local"), (x.value for x in v)))
+
+    def sync(self):
+        _chk(lib().eigenex_context_sync(self.h))
+
+    def profile_enable(self, on=True):
+        _chk(lib().eigenex_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        _chk(lib().eigenex_profile_reset(self.h))
+
+    def profile_get(self, kind: int):
+        n, ms, by = C.c_int64(), C.c_double(), C.c_double()
+        _chk(lib().eigenex_profile_get(self.h, kind, C.byref(n), C.byref(ms), C.byref(by)))
+        return n.value, ms.value, by.value
+
+    def close(self):
+        if self.h:
+            lib().eigenex_context_destroy(self.h)
+            self.h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Csr:
+    def __init__(self, ctx: Context, handle):
+        self.ctx, self.h = ctx, handle
+
+    @classmethod
+    def upload(cls, ctx: Context, n_global: int, rowptr, col, val, row_begin: int = 0):
+        rp = np.ascontiguousarray(rowptr, np.int32)
+        cl = np.ascontiguousarray(col, np.int32)
+        vl = np.ascontiguousarray(val, np.float64)
+        h = _vp()
+        _chk(lib().eigenex_csr_upload(ctx.h, n_global, row_begin, rp.size - 1, _i(rp), _i(cl), _d(vl), C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def laplacian3d(cls, ctx: Context, n: int):
+        h = _vp()
+        _chk(lib().eigenex_csr_laplacian3d(ctx.h, n, C.byref(h)))
+        return cls(ctx, h)
+
+    def info(self):
+        v = [C.c_int64() for _ in range(4)]
+        _chk(lib().eigenex_csr_info(self.h, *[C.byref(x) for x in v]))
+        return dict(zip(("n_global", "n_local", "nnz_local", "n_halo_local"), (x.value for x in v)))
+
+    def close(self):
+        if self.h:
+            lib().eigenex_csr_destroy(self.h)
+            self.h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Basis:
+    """Krylov state on the device (basis slab, work vectors, coefficient arrays)."""
+
+    def __init__(self, ctx: Context, csr: Csr | None, n_global: int, capacity: int, n_ortho: int = 0):
+        self.ctx, self.csr, self.n_global, self.capacity, self.n_ortho = ctx, csr, n_global, capacity, n_ortho
+        self.h = _vp()
+        _chk(lib().eigenex_basis_create(ctx.h, csr.h if csr else None, n_global, capacity, n_ortho, C.byref(self.h)))
+        info = ctx.info()
+        if info["nshards_local"] == info["nshards_total"]:
+            self.n_rows = n_global
+        else:
+            b, e = partition(n_global, info["world_size"], info["rank"])
+            self.n_rows = e - b
+        self._cb = None
+
+    def configure(self, shift=0.0, threshold=1e-12, interval=1, ortho_mode=ORTHO_BATCHED):
+        _chk(lib().eigenex_basis_configure(self.h, shift, threshold, interval, ortho_mode))
+
+    def set_host_operator(self, fn):
+        """fn(x: ndarray) -> ndarray  (the reference's MatMulFunction, lanczos.hpp:116)."""
+        n = self.n_rows
+
+        def tramp(pin, pout, _user):
+            x = np.ctypeslib.as_array(pin, shape=(n,))
+            y = np.ctypeslib.as_array(pout, shape=(n,))
+            y[:] = fn(x)
+
+        self._cb = MATVEC_FN(tramp)
+        _chk(lib().eigenex_basis_set_host_operator(self.h, self._cb, None))
+
+    def clear(self):
+        _chk(lib().eigenex_basis_clear(self.h))
+
+    def upload(self, ref: int, x):
+        x = np.ascontiguousarray(x, np.float64)
+        assert x.size == self.n_rows
+        _chk(lib().eigenex_vec_upload(self.h, ref, _d(x)))
+
+    def download(self, ref: int):
+        x = np.empty(self.n_rows, np.float64)
+        _chk(lib().eigenex_vec_download(self.h, ref, _d(x)))
+        return x
+
+    # -- primitives
+    def apply(self, x_ref, y_ref, shift=0.0, want_dot=False):
+        d = C.c_double()
+        _chk(lib().eigenex_apply(self.h, x_ref, y_ref, shift, C.byref(d) if want_dot else None))
+        return d.value if want_dot else None
+
+    def dots(self, w_ref, first, stride, count, n_ortho_used=0):
+        h = np.zeros(count + n_ortho_used)
+        _chk(lib().eigenex_dots(self.h, w_ref, first, stride, count, n_ortho_used, _d(h)))
+        return h
+
+    def update(self, w_ref, first, stride, count, h, n_ortho_used=0):
+        h = np.ascontiguousarray(h, np.float64)
+        nrm2 = C.c_double()
+        _chk(lib().eigenex_update(self.h, w_ref, first, stride, count, n_ortho_used, _d(h) if h.size else None,
+                                  C.byref(nrm2)))
+        return nrm2.value
+
+    def axpy2(self, z_ref, x_ref, a, p_ref, b, q_ref):
+        _chk(lib().eigenex_axpy2(self.h, z_ref, x_ref, a, p_ref, b, q_ref))
+
+    def scale(self, dst_ref, src_ref, s):
+        _chk(lib().eigenex_scale(self.h, dst_ref, src_ref, s))
+
+    # -- fused steps
+    def lanczos_enqueue(self, ncalls: int):
+        _chk(lib().eigenex_lanczos_enqueue(self.h, ncalls))
+
+    def arnoldi_enqueue(self, ncalls: int):
+        _chk(lib().eigenex_arnoldi_enqueue(self.h, ncalls))
+
+    def lanczos_state(self):
+        st = State()
+        a = np.zeros(self.capacity + 2)
+        b = np.zeros(self.capacity + 2)
+        _chk(lib().eigenex_lanczos_state(self.h, C.byref(st), _d(a), _d(b)))
+        return st, a[: st.nalpha].copy(), b[: st.nbeta].copy()
+
+    def arnoldi_state(self):
+        st = State()
+        ldh = self.capacity + 2
+        H = np.zeros((self.capacity + 1, ldh))  # row c = column c of H
+        _chk(lib().eigenex_arnoldi_state(self.h, C.byref(st), _d(H), ldh))
+        m = min(st.nalpha, self.n_global)
+        return st, H[:m, :m].T.copy()
+
+    def ritz_vectors(self, nvec: int, S):
+        S = np.asfortranarray(S, np.float64)
+        nev = S.shape[1]
+        X = np.zeros((self.n_rows, nev), order="F")
+        if nev:
+            _chk(lib().eigenex_ritz_vectors(self.h, nvec, nev, _d(S), S.shape[0], _d(X), self.n_rows))
+        return X
+
+    def close(self):
+        if self.h:
+            lib().eigenex_basis_destroy(self.h)
+            self.h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

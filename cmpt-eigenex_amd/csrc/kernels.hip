@@ -1,0 +1,659 @@
+// Hand-written gfx950 (CDNA4, wave64) kernels for the Krylov inner loop.
+//
+// Reference operations realised here:
+//   a1/a2/a3  v_ = A*u (+shift*u), alpha = u.v          lanczos.hpp:389-395, :442-448; arnoldi.hpp:333-336, :369-372
+//   a4        w = v_ - alpha_k u_k - beta_{k-1} u_{k-1}  lanczos.hpp:403-408
+//   a5        Gram-Schmidt dots + updates                lanczos.hpp:143-146, :416-425; arnoldi.hpp:96-99, :380-383
+//   a6        beta = ||w||, residue = ||v_||             lanczos.hpp:429; arnoldi.hpp:348, :385
+//   a7        u_{k+1} = w/beta, q_k = v_/residue         lanczos.hpp:439; arnoldi.hpp:365
+//
+// Every kernel is HBM-bound (<= 0.25 flop/byte): no MFMA.  Design rules applied:
+// 16-byte loads (double2) with consecutive lanes on consecutive addresses, several
+// independent loads in flight per lane, wave64 __shfl_down reductions, per-wave LDS
+// accumulators, fixed-order second-stage reductions (bit-reproducible, no float
+// atomics), persistent grids that walk the rows as one frontier so operator-input
+// re-reads are served by L2 / Infinity Cache.
+#include "kernels.hpp"
+
+namespace eigenex {
+
+namespace {
+
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+  return x;  // lane 0 holds the sum
+}
+
+// Sum over the 256-thread block in a fixed order; every thread gets the result.
+__device__ __forceinline__ double block_sum(double x, double* lds4) {
+  x = wave_sum(x);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) lds4[wave] = x;
+  __syncthreads();
+  return (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
+}
+
+__device__ __forceinline__ double2 ld2(const double* p) { return *reinterpret_cast<const double2*>(p); }
+__device__ __forceinline__ void st2(double* p, double2 v) { *reinterpret_cast<double2*>(p) = v; }
+
+__device__ __forceinline__ const double* column_ptr(const ColumnSet& cs, int ci) {
+  return ci < cs.count ? cs.V + (int64_t)(cs.first + ci * cs.stride) * cs.ldv
+                       : cs.Q + (int64_t)(ci - cs.count) * cs.ldq;
+}
+
+// w0 for the 8 rows of this thread in tile `base`: src, or the three-term
+// recurrence (src - a*u_k) - b*u_{k-1} evaluated with explicit fma so that the
+// dots kernel and the update kernel produce bit-identical w0.
+template <bool FULL>
+__device__ __forceinline__ void load_w0(double2 (&w)[4], const double* src, const ThreeTerm& tt,
+                                        double a, double b, int64_t base, int64_t n) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t row = base + i * (2 * kBlock);
+    if (FULL || row < n) {
+      double2 s = ld2(src + row);
+      if (tt.uk) {
+        const double2 u = ld2(tt.uk + row);
+        s.x = fma(-a, u.x, s.x);
+        s.y = fma(-a, u.y, s.y);
+        if (tt.ukm1) {
+          const double2 um = ld2(tt.ukm1 + row);
+          s.x = fma(-b, um.x, s.x);
+          s.y = fma(-b, um.y, s.y);
+        }
+      }
+      w[i] = s;
+    } else {
+      w[i] = make_double2(0.0, 0.0);
+    }
+  }
+}
+
+template <bool FULL>
+__device__ __forceinline__ void load_col(double2 (&x)[4], const double* __restrict__ p, int64_t base, int64_t n) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t row = base + i * (2 * kBlock);
+    x[i] = (FULL || row < n) ? ld2(p + row) : make_double2(0.0, 0.0);
+  }
+}
+
+__device__ __forceinline__ double dot8(const double2 (&w)[4], const double2 (&x)[4]) {
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    s = fma(w[i].x, x[i].x, s);
+    s = fma(w[i].y, x[i].y, s);
+  }
+  return s;
+}
+
+// ---------------------------------------------------------------------------
+// dots: partial h_c = sum_rows col_c[row] * w0[row] for every selected column.
+// One pass over the selected part of the slab; 16 x 16-B loads in flight per lane.
+// ---------------------------------------------------------------------------
+template <bool FULL>
+__device__ __forceinline__ void dots_tile(const double* __restrict__ src, const ThreeTerm& tt, double a, double b,
+                                          const ColumnSet& cs, int ncols, int64_t base, int64_t n, double* wave_acc) {
+  const int lane = threadIdx.x & 63;
+  double2 w[4];
+  load_w0<FULL>(w, src, tt, a, b, base, n);
+  int ci = 0;
+  for (; ci + 4 <= ncols; ci += 4) {
+    double2 x0[4], x1[4], x2[4], x3[4];
+    load_col<FULL>(x0, column_ptr(cs, ci + 0), base, n);
+    load_col<FULL>(x1, column_ptr(cs, ci + 1), base, n);
+    load_col<FULL>(x2, column_ptr(cs, ci + 2), base, n);
+    load_col<FULL>(x3, column_ptr(cs, ci + 3), base, n);
+    double s0 = dot8(w, x0), s1 = dot8(w, x1), s2 = dot8(w, x2), s3 = dot8(w, x3);
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    s3 = wave_sum(s3);
+    if (lane == 0) {
+      wave_acc[ci + 0] += s0;
+      wave_acc[ci + 1] += s1;
+      wave_acc[ci + 2] += s2;
+      wave_acc[ci + 3] += s3;
+    }
+  }
+  for (; ci < ncols; ++ci) {
+    double2 x0[4];
+    load_col<FULL>(x0, column_ptr(cs, ci), base, n);
+    double s0 = wave_sum(dot8(w, x0));
+    if (lane == 0) wave_acc[ci] += s0;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_dots(const double* __restrict__ src, ThreeTerm tt, ColumnSet cs,
+                                                 int64_t n, int64_t ntiles, double* __restrict__ partials,
+                                                 int pstride, const Ctrl* __restrict__ ctrl) {
+  extern __shared__ double lds[];  // [4 waves][ncols]
+  if (ctrl->stopped) return;
+  const int ncols = cs.count + cs.nq;
+  const int wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 4 * ncols; i += kBlock) lds[i] = 0.0;
+  __syncthreads();
+  const double a = tt.uk ? *tt.a : 0.0;
+  const double b = (tt.uk && tt.ukm1) ? *tt.b : 0.0;
+  double* wave_acc = lds + wave * ncols;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t base = tile * kTileRows + 2 * threadIdx.x;
+    if ((tile + 1) * kTileRows <= n)
+      dots_tile<true>(src, tt, a, b, cs, ncols, base, n, wave_acc);
+    else
+      dots_tile<false>(src, tt, a, b, cs, ncols, base, n, wave_acc);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < ncols; c += kBlock)
+    partials[(int64_t)c * pstride + blockIdx.x] = (lds[c] + lds[ncols + c]) + (lds[2 * ncols + c] + lds[3 * ncols + c]);
+}
+
+// ---------------------------------------------------------------------------
+// update: dst = w0 - sum_c h_c * col_c (c ascending, the reference's order of
+// subtraction), fused ||dst||^2.  Second pass over the selected part of the slab.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void axmy8(double2 (&w)[4], double h, const double2 (&x)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    w[i].x = fma(-h, x[i].x, w[i].x);
+    w[i].y = fma(-h, x[i].y, w[i].y);
+  }
+}
+
+template <bool FULL>
+__device__ __forceinline__ double update_tile(const double* src, double* dst,  // may alias (in-place update)
+                                              const ThreeTerm& tt, double a, double b, const ColumnSet& cs, int ncols,
+                                              const double* __restrict__ h, int64_t base, int64_t n) {
+  double2 w[4];
+  load_w0<FULL>(w, src, tt, a, b, base, n);
+  int ci = 0;
+  for (; ci + 4 <= ncols; ci += 4) {
+    double2 x0[4], x1[4], x2[4], x3[4];
+    load_col<FULL>(x0, column_ptr(cs, ci + 0), base, n);
+    load_col<FULL>(x1, column_ptr(cs, ci + 1), base, n);
+    load_col<FULL>(x2, column_ptr(cs, ci + 2), base, n);
+    load_col<FULL>(x3, column_ptr(cs, ci + 3), base, n);
+    axmy8(w, h[ci + 0], x0);
+    axmy8(w, h[ci + 1], x1);
+    axmy8(w, h[ci + 2], x2);
+    axmy8(w, h[ci + 3], x3);
+  }
+  for (; ci < ncols; ++ci) {
+    double2 x0[4];
+    load_col<FULL>(x0, column_ptr(cs, ci), base, n);
+    axmy8(w, h[ci], x0);
+  }
+  double nrm = 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t row = base + i * (2 * kBlock);
+    if (FULL || row < n) {
+      st2(dst + row, w[i]);
+      nrm = fma(w[i].x, w[i].x, nrm);
+      nrm = fma(w[i].y, w[i].y, nrm);
+    }
+  }
+  return nrm;
+}
+
+__global__ __launch_bounds__(kBlock) void k_update(const double* src, double* dst, ThreeTerm tt, ColumnSet cs,
+                                                   const double* __restrict__ h, int64_t n, int64_t ntiles,
+                                                   double* __restrict__ partials, const Ctrl* __restrict__ ctrl) {
+  __shared__ double lds4[4];
+  if (ctrl->stopped) return;
+  const int ncols = cs.count + cs.nq;
+  const double a = tt.uk ? *tt.a : 0.0;
+  const double b = (tt.uk && tt.ukm1) ? *tt.b : 0.0;
+  double nrm = 0.0;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t base = tile * kTileRows + 2 * threadIdx.x;
+    if ((tile + 1) * kTileRows <= n)
+      nrm += update_tile<true>(src, dst, tt, a, b, cs, ncols, h, base, n);
+    else
+      nrm += update_tile<false>(src, dst, tt, a, b, cs, ncols, h, base, n);
+  }
+  nrm = block_sum(nrm, lds4);
+  if (threadIdx.x == 0) partials[blockIdx.x] = nrm;
+}
+
+// ---------------------------------------------------------------------------
+// second-stage reduction: out[c] = sum_b partials[c*pstride + b], one block per
+// column, fixed summation tree (results are reproducible run to run).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_reduce(const double* __restrict__ partials, int pstride, int nblocks,
+                                                   double* __restrict__ out, const Ctrl* __restrict__ ctrl) {
+  __shared__ double lds4[4];
+  if (ctrl->stopped) return;
+  const double* p = partials + (int64_t)blockIdx.x * pstride;
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += kBlock) s += p[b];
+  s = block_sum(s, lds4);
+  if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+
+// ---------------------------------------------------------------------------
+// CSR SpMV, "stream" formulation: a tile of 256 rows owns a contiguous range of
+// stored entries.  Phase 1 streams val/col with aligned 16-B loads (4 entries per
+// lane), gathers x (L2/MALL-served) and parks the rounded products in LDS
+// (index skewed by i>>5 so that the row phase is bank-conflict free for any
+// row length).  Phase 2: one thread per row adds its products in stored order
+// (multiply, then add: bit-identical to the row loop of oracle/krylov_ref.c).
+// Epilogue fuses the shift, the store of the scaled input into the basis slab
+// and the partial dot alpha = u.v.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int skew(int i) { return i + (i >> 5); }
+
+__global__ __launch_bounds__(kBlock) void k_spmv(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                 const double* __restrict__ val, const double* __restrict__ x_ext,
+                                                 const double* __restrict__ scale_ptr, double shift,
+                                                 double* __restrict__ y, double* __restrict__ u_out, int64_t n,
+                                                 int64_t ntiles, double* __restrict__ partials,
+                                                 const Ctrl* __restrict__ ctrl) {
+  __shared__ double prod[kSpmvChunk + kSpmvChunk / 32 + 8];
+  __shared__ double lds4[4];
+  if (ctrl->stopped) return;
+  const double scale = scale_ptr ? *scale_ptr : 1.0;
+  const int tid = threadIdx.x;
+  double dot = 0.0;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t r0 = tile * kSpmvRows;
+    const int64_t r = r0 + tid;
+    int rs = 0, re = 0;
+    if (r < n) {
+      rs = rowptr[r];
+      re = rowptr[r + 1];
+    }
+    const int64_t rend = (r0 + kSpmvRows < n) ? r0 + kSpmvRows : n;
+    const int p0 = rowptr[r0];
+    const int p1 = rowptr[rend];
+    const int pa = p0 & ~3;  // aligned start: int4 / double2 loads
+    double sum = 0.0;
+    for (int cb = pa; cb < p1; cb += kSpmvChunk) {
+      const int cend = (cb + kSpmvChunk < p1) ? cb + kSpmvChunk : p1;
+      // phase 1: entries outside [p0, p1) are valid neighbours' entries or the zero
+      // padding behind nnz; their products are written but never read.
+      for (int q = cb + 4 * tid; q < cend; q += 4 * kBlock) {
+        const int4 c4 = *reinterpret_cast<const int4*>(col + q);
+        const double2 v01 = ld2(val + q);
+        const double2 v23 = ld2(val + q + 2);
+        const double x0 = x_ext[c4.x] * scale;
+        const double x1 = x_ext[c4.y] * scale;
+        const double x2 = x_ext[c4.z] * scale;
+        const double x3 = x_ext[c4.w] * scale;
+        const int li = skew(q - cb);  // 4 consecutive entries never straddle a multiple of 32
+        prod[li + 0] = v01.x * x0;
+        prod[li + 1] = v01.y * x1;
+        prod[li + 2] = v23.x * x2;
+        prod[li + 3] = v23.y * x3;
+      }
+      __syncthreads();
+      // phase 2: stored order, multiply-then-add
+      const int lo = rs > cb ? rs : cb;
+      const int hi = re < cend ? re : cend;
+      for (int p = lo; p < hi; ++p) sum = sum + prod[skew(p - cb)];
+      __syncthreads();
+    }
+    if (r < n) {
+      const double xr = x_ext[r] * scale;
+      double yr = sum;
+      if (shift != 0.0) yr = yr + shift * xr;  // lanczos.hpp:390-392
+      y[r] = yr;
+      if (u_out) u_out[r] = xr;
+      dot = fma(xr, yr, dot);
+    }
+  }
+  if (partials) {
+    dot = block_sum(dot, lds4);
+    if (tid == 0) partials[blockIdx.x] = dot;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_scale(const double* __restrict__ x, const double* __restrict__ scale_dev,
+                                                  double scale_host, double* __restrict__ out, int64_t n,
+                                                  const Ctrl* __restrict__ ctrl) {
+  if (ctrl && ctrl->stopped) return;
+  const double s = scale_dev ? *scale_dev : scale_host;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+    out[i] = x[i] * s;
+}
+
+__global__ __launch_bounds__(kBlock) void k_shift_dot(double* __restrict__ y, const double* __restrict__ u,
+                                                      double shift, int64_t n, double* __restrict__ partials,
+                                                      const Ctrl* __restrict__ ctrl) {
+  __shared__ double lds4[4];
+  if (ctrl->stopped) return;
+  double dot = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const double ui = u[i];
+    double yi = y[i];
+    if (shift != 0.0) {
+      yi = yi + shift * ui;
+      y[i] = yi;
+    }
+    dot = fma(ui, yi, dot);
+  }
+  dot = block_sum(dot, lds4);
+  if (threadIdx.x == 0) partials[blockIdx.x] = dot;
+}
+
+__global__ __launch_bounds__(kBlock) void k_pack(const double* __restrict__ x, const int32_t* __restrict__ idx,
+                                                 int64_t count, double* __restrict__ out,
+                                                 const Ctrl* __restrict__ ctrl) {
+  if (ctrl && ctrl->stopped) return;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += (int64_t)gridDim.x * kBlock)
+    out[i] = x[idx[i]];
+}
+
+__global__ void k_sum_shards(PtrPack bufs, int nshards, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int k = 0; k < nshards; ++k) s += bufs.p[k][i];
+  for (int k = 0; k < nshards; ++k) bufs.p[k][i] = s;
+}
+
+// ---- scalar finalisers -----------------------------------------------------
+__global__ void k_fin_norm(Ctrl* ctrl, const double* nrm2, double threshold, int mode, double* beta) {
+  if (threadIdx.x != 0 || ctrl->stopped) return;
+  const double nrm = sqrt(*nrm2);
+  if (mode == kFinInit) {
+    if (nrm < threshold) {  // lanczos.hpp:316-318, arnoldi.hpp:262-264
+      ctrl->stopped = 1;
+    } else {
+      ctrl->scale = 1.0 / nrm;
+    }
+  } else if (mode == kFinLanczos) {
+    beta[ctrl->nbeta++] = nrm;  // lanczos.hpp:429 (kept on breakdown, :433-436)
+    if (nrm <= threshold)
+      ctrl->stopped = 1;
+    else
+      ctrl->scale = 1.0 / nrm;
+  } else {
+    ctrl->residue = nrm;  // arnoldi.hpp:348, :385
+  }
+}
+
+__global__ void k_fin_alpha(Ctrl* ctrl, const double* val, double* alpha, int first) {
+  if (threadIdx.x != 0 || ctrl->stopped) return;
+  alpha[ctrl->nalpha++] = *val;  // lanczos.hpp:395, :448
+  ctrl->nvec++;
+  ctrl->calls_true++;
+  if (!first) ctrl->iterations++;  // lanczos.hpp:450 (not on the first call, :378-398)
+}
+
+__global__ void k_arnoldi_begin(Ctrl* ctrl, double threshold, int64_t n_global, int cap, double* H, int ldh) {
+  if (threadIdx.x != 0 || ctrl->stopped) return;
+  const int k = ctrl->nvec;
+  // arnoldiStepIsUtmost  arnoldi.hpp:277-288
+  if ((int64_t)k == n_global || ctrl->residue <= threshold || k >= cap) {
+    ctrl->stopped = 1;
+    return;
+  }
+  H[(int64_t)(k - 1) * ldh + k] = ctrl->residue;  // arnoldi.hpp:363
+  ctrl->scale = 1.0 / ctrl->residue;              // arnoldi.hpp:365
+}
+
+__global__ void k_arnoldi_end(Ctrl* ctrl, const double* h, double* H, int ldh) {
+  if (ctrl->stopped) return;
+  const int k = ctrl->nvec;  // index of the vector just added
+  for (int i = threadIdx.x; i <= k; i += blockDim.x) H[(int64_t)k * ldh + i] = h[i];  // arnoldi.hpp:380-383
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    H[(int64_t)k * ldh + k + 1] = 0.0;  // arnoldi.hpp:384
+    ctrl->nvec = k + 1;
+    ctrl->nalpha = k + 1;
+    ctrl->iterations++;
+    ctrl->calls_true++;
+  }
+}
+
+__global__ void k_accept_vector(Ctrl* ctrl) {
+  if (threadIdx.x != 0 || ctrl->stopped) return;
+  ctrl->nvec++;
+}
+
+// ---- synthetic operator ------------------------------------------------------
+// number of stored entries in rows [0, i) of the n^3 7-point Dirichlet Laplacian
+__device__ __forceinline__ int64_t lap_prefix(int64_t i, int64_t n) {
+  const int64_t n2 = n * n, n3 = n2 * n;
+  const int64_t cx0 = (i + n - 1) / n;
+  const int64_t cx1 = i / n;
+  const int64_t m = i % n2;
+  const int64_t cy0 = (i / n2) * n + (m < n ? m : n);
+  const int64_t cy1 = (i / n2) * n + (m > n2 - n ? m - (n2 - n) : 0);
+  const int64_t cz0 = i < n2 ? i : n2;
+  const int64_t cz1 = i > n3 - n2 ? i - (n3 - n2) : 0;
+  return 7 * i - (cx0 + cx1 + cy0 + cy1 + cz0 + cz1);
+}
+
+__global__ __launch_bounds__(kBlock) void k_laplacian3d(int64_t n, int64_t rb, int64_t re, int64_t lower_start,
+                                                        int64_t n_lower, int64_t halo_base,
+                                                        int32_t* __restrict__ rowptr, int32_t* __restrict__ col,
+                                                        double* __restrict__ val) {
+  const int64_t nloc = re - rb;
+  const int64_t n2 = n * n;
+  const int64_t pb = lap_prefix(rb, n);
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i <= nloc; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t r = rb + i;
+    int64_t p = lap_prefix(r, n) - pb;
+    rowptr[i] = (int32_t)p;
+    if (i == nloc) break;
+    const int64_t x = r % n, yy = (r / n) % n, z = r / n2;
+    auto emit = [&](int64_t c, double v) {
+      int64_t lc;
+      if (c >= rb && c < re)
+        lc = c - rb;
+      else if (c < rb)
+        lc = halo_base + (c - lower_start);
+      else
+        lc = halo_base + n_lower + (c - re);
+      col[p] = (int32_t)lc;
+      val[p] = v;
+      ++p;
+    };
+    if (z > 0) emit(r - n2, -1.0);
+    if (yy > 0) emit(r - n, -1.0);
+    if (x > 0) emit(r - 1, -1.0);
+    emit(r, 6.0);
+    if (x < n - 1) emit(r + 1, -1.0);
+    if (yy < n - 1) emit(r + n, -1.0);
+    if (z < n - 1) emit(r + n2, -1.0);
+  }
+}
+
+// ---- Ritz vectors: X = V * S, up to 8 columns per pass over V ----------------
+constexpr int kRitzCols = 8;
+__global__ __launch_bounds__(kBlock) void k_ritz(const double* __restrict__ V, int64_t ldv, int nvec,
+                                                 const double* __restrict__ S, int lds_, int nev,
+                                                 double* __restrict__ X, int64_t ldx, int64_t n, int64_t ntiles,
+                                                 double* __restrict__ partials, int pstride) {
+  __shared__ double lds4[4];
+  double nrm[kRitzCols];
+#pragma unroll
+  for (int e = 0; e < kRitzCols; ++e) nrm[e] = 0.0;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t base = tile * (2 * kBlock) + 2 * threadIdx.x;  // 512 rows per tile
+    if (base >= n) continue;
+    double2 acc[kRitzCols];
+#pragma unroll
+    for (int e = 0; e < kRitzCols; ++e) acc[e] = make_double2(0.0, 0.0);
+    for (int m = 0; m < nvec; ++m) {
+      const double2 v = ld2(V + (int64_t)m * ldv + base);
+#pragma unroll
+      for (int e = 0; e < kRitzCols; ++e) {
+        if (e < nev) {
+          const double s = S[m + (int64_t)e * lds_];
+          acc[e].x = fma(s, v.x, acc[e].x);  // lanczos.hpp:802-804 (m ascending)
+          acc[e].y = fma(s, v.y, acc[e].y);
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < kRitzCols; ++e) {
+      if (e < nev) {
+        double* xp = X + (int64_t)e * ldx + base;
+        xp[0] = acc[e].x;
+        nrm[e] = fma(acc[e].x, acc[e].x, nrm[e]);
+        if (base + 1 < n) {
+          xp[1] = acc[e].y;
+          nrm[e] = fma(acc[e].y, acc[e].y, nrm[e]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < kRitzCols; ++e) {
+    if (e < nev) {
+      const double s = block_sum(nrm[e], lds4);
+      if (threadIdx.x == 0) partials[(int64_t)e * pstride + blockIdx.x] = s;
+    }
+  }
+}
+
+// first local row with |x| > 0 per column: out[2e] = index (n if none), out[2e+1] = value
+__global__ __launch_bounds__(kBlock) void k_first_nonzero(const double* __restrict__ X, int64_t ldx, int64_t n,
+                                                          double* __restrict__ out) {
+  __shared__ long long best[kBlock];
+  const double* x = X + (int64_t)blockIdx.x * ldx;
+  long long found = n;
+  // chunks of 256*16 rows in order; stop at the first chunk that has a hit
+  for (int64_t c0 = 0; c0 < n && found == n; c0 += kBlock * 16) {
+    long long mine = n;
+    for (int j = 0; j < 16; ++j) {
+      const int64_t i = c0 + j * kBlock + threadIdx.x;
+      if (i < n && fabs(x[i]) > 0.0 && i < mine) mine = i;
+    }
+    best[threadIdx.x] = mine;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+      if (threadIdx.x < s && best[threadIdx.x + s] < best[threadIdx.x]) best[threadIdx.x] = best[threadIdx.x + s];
+      __syncthreads();
+    }
+    found = best[0];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = (double)found;
+    out[2 * blockIdx.x + 1] = found < n ? x[found] : 0.0;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_scale_columns(double* __restrict__ X, int64_t ldx, int64_t n,
+                                                          const double* __restrict__ factors) {
+  double* x = X + (int64_t)blockIdx.y * ldx;
+  const double f = factors[blockIdx.y];
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) x[i] *= f;
+}
+
+int g_num_cu = 256;
+
+}  // namespace
+
+int grid_for_tiles(int64_t ntiles, int blocks_per_cu) {
+  int64_t cap = (int64_t)g_num_cu * blocks_per_cu;
+  int64_t g = ntiles < cap ? ntiles : cap;
+  return g < 1 ? 1 : (int)g;
+}
+
+void set_num_cu(int n) { g_num_cu = n > 0 ? n : 256; }
+
+void launch_dots(hipStream_t s, const double* src, ThreeTerm tt, ColumnSet cs, int64_t n, double* partials,
+                 int pstride, int grid, const Ctrl* ctrl) {
+  const int ncols = cs.count + cs.nq;
+  if (ncols <= 0) return;
+  const int64_t ntiles = (n + kTileRows - 1) / kTileRows;
+  const size_t shmem = (size_t)4 * ncols * sizeof(double);
+  hipLaunchKernelGGL(k_dots, dim3(grid), dim3(kBlock), shmem, s, src, tt, cs, n, ntiles, partials, pstride, ctrl);
+}
+
+void launch_update(hipStream_t s, const double* src, double* dst, ThreeTerm tt, ColumnSet cs, const double* h,
+                   int64_t n, double* partials, int grid, const Ctrl* ctrl) {
+  const int64_t ntiles = (n + kTileRows - 1) / kTileRows;
+  hipLaunchKernelGGL(k_update, dim3(grid), dim3(kBlock), 0, s, src, dst, tt, cs, h, n, ntiles, partials, ctrl);
+}
+
+void launch_reduce(hipStream_t s, const double* partials, int pstride, int nblocks, int ncols, double* out,
+                   const Ctrl* ctrl) {
+  if (ncols <= 0) return;
+  hipLaunchKernelGGL(k_reduce, dim3(ncols), dim3(kBlock), 0, s, partials, pstride, nblocks, out, ctrl);
+}
+
+void launch_spmv(hipStream_t s, const int32_t* rowptr, const int32_t* col, const double* val, const double* x_ext,
+                 const double* scale, double shift, double* y, double* u_out, int64_t n, double* partials, int grid,
+                 const Ctrl* ctrl) {
+  const int64_t ntiles = (n + kSpmvRows - 1) / kSpmvRows;
+  hipLaunchKernelGGL(k_spmv, dim3(grid), dim3(kBlock), 0, s, rowptr, col, val, x_ext, scale, shift, y, u_out, n,
+                     ntiles, partials, ctrl);
+}
+
+void launch_scale(hipStream_t s, const double* x, const double* scale_dev, double scale_host, double* out, int64_t n,
+                  const Ctrl* ctrl) {
+  const int grid = grid_for_tiles((n + kBlock - 1) / kBlock, 8);
+  hipLaunchKernelGGL(k_scale, dim3(grid), dim3(kBlock), 0, s, x, scale_dev, scale_host, out, n, ctrl);
+}
+
+void launch_shift_dot(hipStream_t s, double* y, const double* u, double shift, int64_t n, double* partials, int grid,
+                      const Ctrl* ctrl) {
+  hipLaunchKernelGGL(k_shift_dot, dim3(grid), dim3(kBlock), 0, s, y, u, shift, n, partials, ctrl);
+}
+
+void launch_pack(hipStream_t s, const double* x, const int32_t* idx, int64_t count, double* out, const Ctrl* ctrl) {
+  if (count <= 0) return;
+  const int grid = grid_for_tiles((count + kBlock - 1) / kBlock, 8);
+  hipLaunchKernelGGL(k_pack, dim3(grid), dim3(kBlock), 0, s, x, idx, count, out, ctrl);
+}
+
+void launch_sum_shards(hipStream_t s, const PtrPack& bufs, int nshards, int n) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_sum_shards, dim3((n + 63) / 64), dim3(64), 0, s, bufs, nshards, n);
+}
+
+void launch_fin_norm(hipStream_t s, Ctrl* ctrl, const double* nrm2, double threshold, int mode, double* beta) {
+  hipLaunchKernelGGL(k_fin_norm, dim3(1), dim3(64), 0, s, ctrl, nrm2, threshold, mode, beta);
+}
+
+void launch_fin_alpha(hipStream_t s, Ctrl* ctrl, const double* val, double* alpha, int first, int /*cap*/) {
+  hipLaunchKernelGGL(k_fin_alpha, dim3(1), dim3(64), 0, s, ctrl, val, alpha, first);
+}
+
+void launch_arnoldi_begin(hipStream_t s, Ctrl* ctrl, double threshold, int64_t n_global, int cap, double* H,
+                          int ldh) {
+  hipLaunchKernelGGL(k_arnoldi_begin, dim3(1), dim3(64), 0, s, ctrl, threshold, n_global, cap, H, ldh);
+}
+
+void launch_arnoldi_end(hipStream_t s, Ctrl* ctrl, const double* h, double* H, int ldh) {
+  hipLaunchKernelGGL(k_arnoldi_end, dim3(1), dim3(kBlock), 0, s, ctrl, h, H, ldh);
+}
+
+void launch_accept_vector(hipStream_t s, Ctrl* ctrl) {
+  hipLaunchKernelGGL(k_accept_vector, dim3(1), dim3(64), 0, s, ctrl);
+}
+
+void launch_laplacian3d(hipStream_t s, int64_t n, int64_t rb, int64_t re, int64_t lower_start, int64_t n_lower,
+                        int64_t halo_base, int32_t* rowptr, int32_t* col, double* val) {
+  const int64_t work = re - rb + 1;
+  const int grid = grid_for_tiles((work + kBlock - 1) / kBlock, 8);
+  hipLaunchKernelGGL(k_laplacian3d, dim3(grid), dim3(kBlock), 0, s, n, rb, re, lower_start, n_lower, halo_base, rowptr,
+                     col, val);
+}
+
+void launch_ritz(hipStream_t s, const double* V, int64_t ldv, int nvec, const double* S_dev, int lds, int nev,
+                 double* X, int64_t ldx, int64_t n, double* partials, int pstride, int grid) {
+  const int64_t ntiles = (n + 2 * kBlock - 1) / (2 * kBlock);
+  hipLaunchKernelGGL(k_ritz, dim3(grid), dim3(kBlock), 0, s, V, ldv, nvec, S_dev, lds, nev, X, ldx, n, ntiles,
+                     partials, pstride);
+}
+
+void launch_first_nonzero(hipStream_t s, const double* X, int64_t ldx, int nev, int64_t n, double* out_idx_val) {
+  hipLaunchKernelGGL(k_first_nonzero, dim3(nev), dim3(kBlock), 0, s, X, ldx, n, out_idx_val);
+}
+
+void launch_scale_columns(hipStream_t s, double* X, int64_t ldx, int nev, int64_t n, const double* factors_dev) {
+  const int gx = grid_for_tiles((n + kBlock - 1) / kBlock, 4);
+  hipLaunchKernelGGL(k_scale_columns, dim3(gx, nev), dim3(kBlock), 0, s, X, ldx, n, factors_dev);
+}
+
+}  // namespace eigenex

@@ -1,0 +1,102 @@
+// Kernel launch interface of the gfx950 Krylov step library (internal).
+// Everything here is stream-ordered and never synchronises.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace eigenex {
+
+// Device-resident control block of one Krylov state (replicated on every shard:
+// all shards see identical all-reduced scalars, so they take identical decisions).
+struct Ctrl {
+  int stopped;     // a step returned false on the device; later kernels are no-ops
+  int nvec;        // lanczosvectors_.size() / arnoldivectors_.size()
+  int nalpha;      // alpha_.size() / h_.size()
+  int nbeta;       // beta_.size()
+  int iterations;  // iterations_
+  int calls_true;  // calls that returned true
+  int pad0, pad1;
+  double scale;    // 1/beta_k or 1/residue_: factor applied to the operator input
+  double residue;  // Arnoldi residue_
+};
+
+constexpr int kBlock = 256;          // threads per workgroup (4 wave64)
+constexpr int kRowsPerThread = 8;    // vector kernels: 4 x double2 per thread per column
+constexpr int kTileRows = kBlock * kRowsPerThread;  // 2048 rows per tile
+constexpr int kSpmvRows = 256;       // SpMV: rows per tile (one row per thread in the row phase)
+constexpr int kSpmvChunk = 2048;     // SpMV: products staged in LDS per chunk
+
+struct ColumnSet {     // which vectors a dots/update pass runs over, in reference order
+  const double* V;     // basis slab, column c at V + c*ldv
+  int64_t ldv;
+  int first, stride, count;   // basis columns first, first+stride, ... (count of them)
+  const double* Q;     // orthogonalizingVectors_ slab
+  int64_t ldq;
+  int nq;
+};
+
+struct ThreeTerm {     // w0 = src - a*u_k - b*u_{k-1}   (lanczos.hpp:403-408); disabled if uk == nullptr
+  const double* uk;
+  const double* ukm1;  // nullptr for k == 0
+  const double* a;     // device scalars
+  const double* b;
+};
+
+int grid_for_tiles(int64_t ntiles, int blocks_per_cu);
+void set_num_cu(int n);
+
+// partials[c*pstride + block], c < ncols: per-block partial dot of w0 with column c
+void launch_dots(hipStream_t s, const double* src, ThreeTerm tt, ColumnSet cs, int64_t n, double* partials,
+                 int pstride, int grid, const Ctrl* ctrl);
+// dst = w0 - sum_c h[c]*col_c (sequential in c); partials[block] = partial ||dst||^2
+void launch_update(hipStream_t s, const double* src, double* dst, ThreeTerm tt, ColumnSet cs, const double* h,
+                   int64_t n, double* partials, int grid, const Ctrl* ctrl);
+// out[c] = sum_b partials[c*pstride + b], fixed order (deterministic second stage)
+void launch_reduce(hipStream_t s, const double* partials, int pstride, int nblocks, int ncols, double* out,
+                   const Ctrl* ctrl);
+// y = A*(x*scale) + shift*(x*scale); u_out = x*scale (optional); partials[block] = partial (x*scale).y (optional)
+void launch_spmv(hipStream_t s, const int32_t* rowptr, const int32_t* col, const double* val, const double* x_ext,
+                 const double* scale, double shift, double* y, double* u_out, int64_t n, double* partials, int grid,
+                 const Ctrl* ctrl);
+// host-operator path: u_out = x*scale
+void launch_scale(hipStream_t s, const double* x, const double* scale_dev, double scale_host, double* out, int64_t n,
+                  const Ctrl* ctrl);
+// host-operator path: y += shift*u ; partials[block] = partial u.y
+void launch_shift_dot(hipStream_t s, double* y, const double* u, double shift, int64_t n, double* partials, int grid,
+                      const Ctrl* ctrl);
+// gather send buffer: out[i] = x[idx[i]]
+void launch_pack(hipStream_t s, const double* x, const int32_t* idx, int64_t count, double* out, const Ctrl* ctrl);
+// loopback all-reduce: every p[s][i] = sum_s p[s][i] (fixed order); pointers travel as kernel arguments
+constexpr int kMaxLoopbackShards = 64;
+struct PtrPack {
+  double* p[kMaxLoopbackShards];
+};
+void launch_sum_shards(hipStream_t s, const PtrPack& bufs, int nshards, int n);
+
+// ---- scalar finalisers (one thread) ----
+enum FinNormMode { kFinInit = 0, kFinLanczos = 1, kFinArnoldi = 2 };
+// nrm2 = ||w||^2 (all-reduced).  kFinInit: fail if sqrt < threshold, else scale = 1/nrm.
+// kFinLanczos: beta.push_back(sqrt); breakdown if <= threshold else scale = 1/beta.
+// kFinArnoldi: residue = sqrt.
+void launch_fin_norm(hipStream_t s, Ctrl* ctrl, const double* nrm2, double threshold, int mode, double* beta);
+// Lanczos: alpha.push_back(*val); counts as a successful call; first==1: no iteration increment
+void launch_fin_alpha(hipStream_t s, Ctrl* ctrl, const double* val, double* alpha, int first, int cap);
+// Arnoldi start of a later call: stop if residue <= threshold or basis full, else H[k][k-1] = residue, scale = 1/residue
+void launch_arnoldi_begin(hipStream_t s, Ctrl* ctrl, double threshold, int64_t n_global, int cap, double* H, int ldh);
+// Arnoldi end of a call: H[0..k][k] = h[0..k], H[k+1][k] = 0, ++iterations
+void launch_arnoldi_end(hipStream_t s, Ctrl* ctrl, const double* h, double* H, int ldh);
+// vector accepted into the basis: ++nvec  (after the operator has been applied with `scale`)
+void launch_accept_vector(hipStream_t s, Ctrl* ctrl);
+
+// synthetic 7-point Laplacian rows [rb, re) of an n^3 grid; cols remapped to local/halo numbering
+void launch_laplacian3d(hipStream_t s, int64_t n, int64_t rb, int64_t re, int64_t lower_start, int64_t n_lower,
+                        int64_t halo_base, int32_t* rowptr, int32_t* col, double* val);
+
+// Ritz vectors: X[:, e] = sum_m S[m + e*lds] * V[:, m]  for e < nev (<= 8 per launch); partial norms
+void launch_ritz(hipStream_t s, const double* V, int64_t ldv, int nvec, const double* S_dev, int lds, int nev,
+                 double* X, int64_t ldx, int64_t n, double* partials, int pstride, int grid);
+// per column: first local index with a non-zero entry (n if none) and its value
+void launch_first_nonzero(hipStream_t s, const double* X, int64_t ldx, int nev, int64_t n, double* out_idx_val);
+void launch_scale_columns(hipStream_t s, double* X, int64_t ldx, int nev, int64_t n, const double* factors_dev);
+
+}  // namespace eigenex

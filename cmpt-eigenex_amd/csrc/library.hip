@@ -1,0 +1,1317 @@
+// C ABI of the gfx950 Krylov step library (include/eigenex_hip.h): contexts,
+// transports (RCCL between processes / loopback inside one process), CSR row
+// shards with halo plans, Krylov state and the step drivers that enqueue the
+// kernels of kernels.hip.  Reference call sites are cited per function.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/eigenex_hip.h"
+#include "kernels.hpp"
+
+using namespace eigenex;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess)                                                                              \
+      return fail(EIGENEX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" + __FILE__ + ":" + \
+                                       std::to_string(__LINE__) + ")");                                \
+  } while (0)
+
+#define NCCLCHK(expr)                                                                                    \
+  do {                                                                                                   \
+    ncclResult_t r_ = (expr);                                                                            \
+    if (r_ != ncclSuccess)                                                                               \
+      return fail(EIGENEX_ERR_RCCL, std::string(#expr) + ": " + ncclGetErrorString(r_) + " (" + __FILE__ + ":" + \
+                                        std::to_string(__LINE__) + ")");                                 \
+  } while (0)
+
+#define CHK(expr)            \
+  do {                       \
+    int rc_ = (expr);        \
+    if (rc_ != 0) return rc_; \
+  } while (0)
+
+inline int64_t pad_rows(int64_t n) { return (n + 63) / 64 * 64; }
+
+inline void partition(int64_t n, int P, int s, int64_t* b, int64_t* e) {
+  *b = (int64_t)((__int128)n * s / P);
+  *e = (int64_t)((__int128)n * (s + 1) / P);
+}
+
+inline int owner_of(int64_t n, int P, int64_t c) {
+  int s = (int)((__int128)c * P / n);
+  if (s >= P) s = P - 1;
+  int64_t b, e;
+  for (;;) {
+    partition(n, P, s, &b, &e);
+    if (c < b)
+      --s;
+    else if (c >= e)
+      ++s;
+    else
+      return s;
+  }
+}
+
+// ---------------------------------------------------------------------------
+struct ProfRec {
+  int kind;
+  double bytes;
+  hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct eigenex_context_s {
+  int device = 0;
+  int rank = 0, world = 1;
+  bool loopback = false;
+  int P = 1;                      // shards in the partition
+  std::vector<int> local;         // global ids of the shards this context owns
+  hipStream_t stream = nullptr;
+  ncclComm_t comm = nullptr;
+  bool profiling = false;
+  std::vector<ProfRec> recs;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+  size_t pool_used = 0;
+  double acc_ms[EIGENEX_K_COUNT] = {0};
+  double acc_bytes[EIGENEX_K_COUNT] = {0};
+  int64_t acc_n[EIGENEX_K_COUNT] = {0};
+};
+
+namespace {
+
+struct ProfScope {
+  eigenex_context_s* c;
+  bool on;
+  hipEvent_t b = nullptr;
+  ProfScope(eigenex_context_s* ctx, int kind, double bytes) : c(ctx), on(ctx->profiling) {
+    if (!on) return;
+    if (c->pool_used == c->pool.size()) {
+      hipEvent_t x, y;
+      if (hipEventCreate(&x) != hipSuccess || hipEventCreate(&y) != hipSuccess) {
+        on = false;
+        return;
+      }
+      c->pool.push_back({x, y});
+    }
+    auto pr = c->pool[c->pool_used++];
+    b = pr.second;
+    hipEventRecord(pr.first, c->stream);
+    c->recs.push_back({kind, bytes, pr.first, pr.second});
+  }
+  ~ProfScope() {
+    if (on) hipEventRecord(b, c->stream);
+  }
+};
+
+int prof_collect(eigenex_context_s* c) {
+  if (c->recs.empty()) return 0;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (auto& r : c->recs) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
+    c->acc_ms[r.kind] += ms;
+    c->acc_bytes[r.kind] += r.bytes;
+    c->acc_n[r.kind] += 1;
+  }
+  c->recs.clear();
+  c->pool_used = 0;
+  return 0;
+}
+
+struct Segment {  // one contiguous piece of a halo exchange with one peer
+  int peer;       // global shard id
+  int64_t offset; // recv: offset into the halo region; send: offset into send_idx / sendbuf
+  int64_t count;
+  int64_t contig_start;  // send only: >= 0 if the indices are consecutive local rows starting here
+};
+
+struct CsrShard {
+  int gshard = 0;
+  int64_t rb = 0, re = 0, nloc = 0, npad = 0, nnz = 0, nhalo = 0;
+  int32_t* rowptr = nullptr;
+  int32_t* col = nullptr;
+  double* val = nullptr;
+  std::vector<Segment> recv, send;
+  int32_t* send_idx = nullptr;  // device, concatenated local row indices
+  double* sendbuf = nullptr;    // device
+  int64_t nsend = 0;
+  std::vector<int32_t> halo_cols;  // global column of each halo slot (host copy, small cases / tests)
+};
+
+}  // namespace
+
+struct eigenex_csr_s {
+  eigenex_context_s* ctx = nullptr;
+  int64_t n_global = 0;
+  std::vector<CsrShard> sh;
+};
+
+namespace {
+
+struct BasisShard {
+  int gshard = 0;
+  int64_t rb = 0, nloc = 0, ldv = 0, nhalo = 0;
+  CsrShard* csr = nullptr;
+  double *V = nullptr, *Q = nullptr, *v = nullptr, *w = nullptr;
+  double *partials = nullptr, *hbuf = nullptr, *alpha = nullptr, *beta = nullptr, *H = nullptr;
+  double* X = nullptr;  // Ritz vector scratch (ldv x 8), lazy
+  Ctrl* ctrl = nullptr;
+  Ctrl* ctrl_zero = nullptr;  // always-zero control block for the stand-alone primitives
+  int g_vec = 1, g_spmv = 1, pstride = 1;
+};
+
+}  // namespace
+
+struct eigenex_basis_s {
+  eigenex_context_s* ctx = nullptr;
+  eigenex_csr_s* csr = nullptr;
+  int64_t n_global = 0;
+  int cap = 0, nq = 0, maxcols = 0, ldh = 0;
+  double shift = 0.0, threshold = 1e-12;
+  int64_t interval = 1;
+  int ortho_mode = EIGENEX_ORTHO_BATCHED;
+  std::vector<BasisShard> sh;
+  bool started = false;
+  int h_nvec = 0;
+  eigenex_matvec_fn fn = nullptr;
+  void* fn_user = nullptr;
+  double *pin_in = nullptr, *pin_out = nullptr;
+  Ctrl* pin_ctrl = nullptr;
+  int slot_nrm() const { return maxcols; }
+  int slot_alpha() const { return maxcols + 1; }
+  int slot_a() const { return maxcols + 2; }
+  int slot_b() const { return maxcols + 3; }
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// transports
+// ---------------------------------------------------------------------------
+// in-place sum over all shards of hbuf[off .. off+n) on every shard
+int allreduce(eigenex_basis_s* b, int off, int n) {
+  eigenex_context_s* c = b->ctx;
+  if (c->P == 1 || n <= 0) return 0;
+  ProfScope ps(c, EIGENEX_K_COMM, 0.0);
+  if (c->loopback) {
+    PtrPack pk;
+    for (size_t s = 0; s < b->sh.size(); ++s) pk.p[s] = b->sh[s].hbuf + off;
+    launch_sum_shards(c->stream, pk, (int)b->sh.size(), n);
+    return 0;
+  }
+  double* p = b->sh[0].hbuf + off;
+  NCCLCHK(ncclAllReduce(p, p, (size_t)n, ncclDouble, ncclSum, c->comm, c->stream));
+  return 0;
+}
+
+// fill the halo region of every local shard's operator-input vector
+int halo_exchange(eigenex_basis_s* b, bool use_ctrl = true) {
+  eigenex_context_s* c = b->ctx;
+  if (c->P == 1 || !b->csr) return 0;
+  ProfScope ps(c, EIGENEX_K_COMM, 0.0);
+  // pack non-contiguous send segments
+  for (auto& bs : b->sh) {
+    CsrShard* cs = bs.csr;
+    for (auto& sg : cs->send)
+      if (sg.contig_start < 0)
+        launch_pack(c->stream, bs.w, cs->send_idx + sg.offset, sg.count, cs->sendbuf + sg.offset,
+                    use_ctrl ? bs.ctrl : bs.ctrl_zero);
+  }
+  if (c->loopback) {
+    for (auto& bs : b->sh) {
+      CsrShard* cs = bs.csr;
+      for (auto& rg : cs->recv) {
+        BasisShard& src = b->sh[rg.peer];
+        const Segment* sg = nullptr;
+        for (auto& x : src.csr->send)
+          if (x.peer == bs.gshard) sg = &x;
+        if (!sg || sg->count != rg.count) return fail(EIGENEX_ERR_STATE, "halo plan mismatch");
+        const double* sp = sg->contig_start >= 0 ? src.w + sg->contig_start : src.csr->sendbuf + sg->offset;
+        HIPCHK(hipMemcpyAsync(bs.w + bs.ldv + rg.offset, sp, sizeof(double) * rg.count, hipMemcpyDeviceToDevice,
+                              c->stream));
+      }
+    }
+    return 0;
+  }
+  BasisShard& bs = b->sh[0];
+  CsrShard* cs = bs.csr;
+  if (cs->send.empty() && cs->recv.empty()) return 0;
+  NCCLCHK(ncclGroupStart());
+  for (auto& sg : cs->send) {
+    const double* sp = sg.contig_start >= 0 ? bs.w + sg.contig_start : cs->sendbuf + sg.offset;
+    NCCLCHK(ncclSend(sp, (size_t)sg.count, ncclDouble, sg.peer, c->comm, c->stream));
+  }
+  for (auto& rg : cs->recv)
+    NCCLCHK(ncclRecv(bs.w + bs.ldv + rg.offset, (size_t)rg.count, ncclDouble, rg.peer, c->comm, c->stream));
+  NCCLCHK(ncclGroupEnd());
+  return 0;
+}
+
+void free_csr_shard(CsrShard& s) {
+  if (s.rowptr) (void)hipFree(s.rowptr);
+  if (s.col) (void)hipFree(s.col);
+  if (s.val) (void)hipFree(s.val);
+  if (s.send_idx) (void)hipFree(s.send_idx);
+  if (s.sendbuf) (void)hipFree(s.sendbuf);
+  s = CsrShard();
+}
+
+// recv segments from the sorted halo column list: one segment per owner
+void build_recv(CsrShard& s, int64_t n_global, int P) {
+  s.recv.clear();
+  int64_t i = 0;
+  const int64_t nh = (int64_t)s.halo_cols.size();
+  while (i < nh) {
+    const int o = owner_of(n_global, P, s.halo_cols[i]);
+    int64_t ob, oe;
+    partition(n_global, P, o, &ob, &oe);
+    int64_t j = i;
+    while (j < nh && s.halo_cols[j] < oe) ++j;
+    s.recv.push_back({o, i, j - i, -1});
+    i = j;
+  }
+}
+
+// install the list of my rows (global numbering, ascending) that peer needs
+int add_send(CsrShard& s, int peer, const int32_t* cols_global, int64_t count, std::vector<int32_t>& idx_host) {
+  if (count == 0) return 0;
+  Segment sg{peer, (int64_t)idx_host.size(), count, -1};
+  bool contig = true;
+  for (int64_t i = 0; i < count; ++i) {
+    const int64_t c = cols_global[i];
+    if (c < s.rb || c >= s.re) return fail(EIGENEX_ERR_STATE, "halo request for a row this shard does not own");
+    if (i > 0 && cols_global[i] != cols_global[i - 1] + 1) contig = false;
+    idx_host.push_back((int32_t)(c - s.rb));
+  }
+  if (contig) sg.contig_start = cols_global[0] - s.rb;
+  s.send.push_back(sg);
+  return 0;
+}
+
+int finish_send(eigenex_context_s* c, CsrShard& s, const std::vector<int32_t>& idx_host) {
+  s.nsend = (int64_t)idx_host.size();
+  if (s.nsend == 0) return 0;
+  HIPCHK(hipMalloc(&s.send_idx, sizeof(int32_t) * s.nsend));
+  HIPCHK(hipMalloc(&s.sendbuf, sizeof(double) * s.nsend));
+  HIPCHK(hipMemcpyAsync(s.send_idx, idx_host.data(), sizeof(int32_t) * s.nsend, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// Host-side shard construction from user CSR arrays (global columns).
+int build_shard_host(eigenex_context_s* c, int64_t n_global, int gshard, const int32_t* rowptr, const int32_t* col,
+                     const double* val, CsrShard& s) {
+  s.gshard = gshard;
+  partition(n_global, c->P, gshard, &s.rb, &s.re);
+  s.nloc = s.re - s.rb;
+  s.npad = pad_rows(s.nloc);
+  const int64_t p0 = rowptr[0];
+  s.nnz = (int64_t)rowptr[s.nloc] - p0;
+  if (s.nnz < 0 || s.nnz > (int64_t)2147483647 - 16384) return fail(EIGENEX_ERR_ARG, "nnz of a shard must be < 2^31 - 16384");
+  std::vector<int32_t> rem;
+  for (int64_t p = 0; p < s.nnz; ++p) {
+    const int64_t cg = col[p0 + p];
+    if (cg < 0 || cg >= n_global) return fail(EIGENEX_ERR_ARG, "column index out of range");
+    if (cg < s.rb || cg >= s.re) rem.push_back((int32_t)cg);
+  }
+  std::sort(rem.begin(), rem.end());
+  rem.erase(std::unique(rem.begin(), rem.end()), rem.end());
+  s.halo_cols.swap(rem);
+  s.nhalo = (int64_t)s.halo_cols.size();
+  if (s.npad + s.nhalo > 2147483647) return fail(EIGENEX_ERR_ARG, "local + halo columns exceed int32");
+  std::vector<int32_t> lcol((size_t)s.nnz + 8, 0);
+  for (int64_t p = 0; p < s.nnz; ++p) {
+    const int64_t cg = col[p0 + p];
+    if (cg >= s.rb && cg < s.re)
+      lcol[p] = (int32_t)(cg - s.rb);
+    else
+      lcol[p] = (int32_t)(s.npad + (std::lower_bound(s.halo_cols.begin(), s.halo_cols.end(), (int32_t)cg) -
+                                    s.halo_cols.begin()));
+  }
+  std::vector<int32_t> lrp((size_t)s.nloc + 1);
+  for (int64_t i = 0; i <= s.nloc; ++i) lrp[i] = (int32_t)(rowptr[i] - p0);
+  HIPCHK(hipMalloc(&s.rowptr, sizeof(int32_t) * (s.nloc + 1)));
+  HIPCHK(hipMalloc(&s.col, sizeof(int32_t) * (s.nnz + 8)));
+  HIPCHK(hipMalloc(&s.val, sizeof(double) * (s.nnz + 8)));
+  HIPCHK(hipMemsetAsync(s.val, 0, sizeof(double) * (s.nnz + 8), c->stream));
+  HIPCHK(hipMemcpyAsync(s.rowptr, lrp.data(), sizeof(int32_t) * (s.nloc + 1), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(s.col, lcol.data(), sizeof(int32_t) * (s.nnz + 8), hipMemcpyHostToDevice, c->stream));
+  if (s.nnz) HIPCHK(hipMemcpyAsync(s.val, val + p0, sizeof(double) * s.nnz, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  build_recv(s, n_global, c->P);
+  return 0;
+}
+
+// RCCL: tell every owner which of its rows this rank needs (collective).
+int exchange_send_lists_rccl(eigenex_context_s* c, int64_t /*n_global*/, CsrShard& s) {
+  const int P = c->P;
+  std::vector<int32_t> need_cnt((size_t)P, 0);
+  for (auto& rg : s.recv) need_cnt[rg.peer] = (int32_t)rg.count;
+  int32_t *d_cnt = nullptr, *d_all = nullptr;
+  HIPCHK(hipMalloc(&d_cnt, sizeof(int32_t) * P));
+  HIPCHK(hipMalloc(&d_all, sizeof(int32_t) * P * P));
+  HIPCHK(hipMemcpyAsync(d_cnt, need_cnt.data(), sizeof(int32_t) * P, hipMemcpyHostToDevice, c->stream));
+  NCCLCHK(ncclAllGather(d_cnt, d_all, (size_t)P, ncclInt32, c->comm, c->stream));
+  std::vector<int32_t> all((size_t)P * P);
+  HIPCHK(hipMemcpyAsync(all.data(), d_all, sizeof(int32_t) * P * P, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  // all[r*P + o] = number of rows of owner o that rank r needs
+  int64_t nrecv_total = 0;
+  for (int r = 0; r < P; ++r)
+    if (r != c->rank) nrecv_total += all[(size_t)r * P + c->rank];
+  int32_t *d_need = nullptr, *d_req = nullptr;
+  if (s.nhalo) {
+    HIPCHK(hipMalloc(&d_need, sizeof(int32_t) * s.nhalo));
+    HIPCHK(hipMemcpyAsync(d_need, s.halo_cols.data(), sizeof(int32_t) * s.nhalo, hipMemcpyHostToDevice, c->stream));
+  }
+  if (nrecv_total) HIPCHK(hipMalloc(&d_req, sizeof(int32_t) * nrecv_total));
+  NCCLCHK(ncclGroupStart());
+  for (auto& rg : s.recv)
+    NCCLCHK(ncclSend(d_need + rg.offset, (size_t)rg.count, ncclInt32, rg.peer, c->comm, c->stream));
+  int64_t off = 0;
+  for (int r = 0; r < P; ++r) {
+    const int64_t cnt = r == c->rank ? 0 : all[(size_t)r * P + c->rank];
+    if (cnt) NCCLCHK(ncclRecv(d_req + off, (size_t)cnt, ncclInt32, r, c->comm, c->stream));
+    off += cnt;
+  }
+  NCCLCHK(ncclGroupEnd());
+  std::vector<int32_t> req((size_t)nrecv_total);
+  if (nrecv_total)
+    HIPCHK(hipMemcpyAsync(req.data(), d_req, sizeof(int32_t) * nrecv_total, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  std::vector<int32_t> idx_host;
+  off = 0;
+  for (int r = 0; r < P; ++r) {
+    const int64_t cnt = r == c->rank ? 0 : all[(size_t)r * P + c->rank];
+    CHK(add_send(s, r, req.data() + off, cnt, idx_host));
+    off += cnt;
+  }
+  CHK(finish_send(c, s, idx_host));
+  (void)hipFree(d_cnt);
+  (void)hipFree(d_all);
+  if (d_need) (void)hipFree(d_need);
+  if (d_req) (void)hipFree(d_req);
+  return 0;
+}
+
+int build_send_lists_loopback(eigenex_context_s* c, eigenex_csr_s* m) {
+  for (auto& s : m->sh) {
+    std::vector<int32_t> idx_host;
+    for (auto& peer : m->sh) {
+      if (peer.gshard == s.gshard) continue;
+      for (auto& rg : peer.recv)
+        if (rg.peer == s.gshard) CHK(add_send(s, peer.gshard, peer.halo_cols.data() + rg.offset, rg.count, idx_host));
+    }
+    CHK(finish_send(c, s, idx_host));
+  }
+  return 0;
+}
+
+double* vec_ptr(BasisShard& s, int cap, int nq, int ref) {
+  if (ref >= 0) return ref < cap ? s.V + (int64_t)ref * s.ldv : nullptr;
+  if (ref == EIGENEX_VEC_V) return s.v;
+  if (ref == EIGENEX_VEC_W) return s.w;
+  const int q = -16 - ref;
+  if (q >= 0 && q < nq) return s.Q + (int64_t)q * s.ldv;
+  return nullptr;
+}
+
+ColumnSet colset(BasisShard& s, int first, int stride, int count, int qfirst, int nq) {
+  ColumnSet cs;
+  cs.V = s.V;
+  cs.ldv = s.ldv;
+  cs.first = first;
+  cs.stride = stride;
+  cs.count = count;
+  cs.Q = s.Q ? s.Q + (int64_t)qfirst * s.ldv : nullptr;
+  cs.ldq = s.ldv;
+  cs.nq = nq;
+  return cs;
+}
+
+// ---- enqueue helpers (all local shards, then the collective) -----------------
+// h[slot .. slot+ncols) = all-reduced dots of w0(src, tt) with the column set
+int enq_dots(eigenex_basis_s* b, int src_ref, bool three_term, int k, int first, int stride, int count, int qfirst,
+             int nq, int slot, bool use_ctrl) {
+  eigenex_context_s* c = b->ctx;
+  const int ncols = count + nq;
+  if (ncols <= 0) return 0;
+  for (auto& s : b->sh) {
+    ThreeTerm tt{nullptr, nullptr, nullptr, nullptr};
+    if (three_term) tt = ThreeTerm{s.V + (int64_t)k * s.ldv, k > 0 ? s.V + (int64_t)(k - 1) * s.ldv : nullptr, s.alpha + k, s.beta + (k > 0 ? k - 1 : 0)};
+    const Ctrl* ctl = use_ctrl ? s.ctrl : s.ctrl_zero;
+    {
+      ProfScope ps(c, EIGENEX_K_DOTS, 8.0 * s.nloc * ncols + 8.0 * s.nloc);
+      launch_dots(c->stream, vec_ptr(s, b->cap, b->nq, src_ref), tt, colset(s, first, stride, count, qfirst, nq), s.nloc,
+                  s.partials, s.pstride, s.g_vec, ctl);
+    }
+    ProfScope ps(c, EIGENEX_K_SMALL, 0.0);
+    launch_reduce(c->stream, s.partials, s.pstride, s.g_vec, ncols, s.hbuf + slot, ctl);
+  }
+  return allreduce(b, slot, ncols);
+}
+
+// dst = w0(src, tt) - sum h[slot+c]*col_c ; hbuf[slot_nrm] = all-reduced ||dst||^2 (if want_norm)
+int enq_update(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_term, int k, int first, int stride, int count,
+               int qfirst, int nq, int slot, bool want_norm, bool use_ctrl) {
+  eigenex_context_s* c = b->ctx;
+  const int ncols = count + nq;
+  for (auto& s : b->sh) {
+    ThreeTerm tt{nullptr, nullptr, nullptr, nullptr};
+    if (three_term) tt = ThreeTerm{s.V + (int64_t)k * s.ldv, k > 0 ? s.V + (int64_t)(k - 1) * s.ldv : nullptr, s.alpha + k, s.beta + (k > 0 ? k - 1 : 0)};
+    const Ctrl* ctl = use_ctrl ? s.ctrl : s.ctrl_zero;
+    {
+      ProfScope ps(c, EIGENEX_K_UPDATE, 8.0 * s.nloc * ncols + 24.0 * s.nloc + (three_term ? 32.0 * s.nloc : 0.0));
+      launch_update(c->stream, vec_ptr(s, b->cap, b->nq, src_ref), vec_ptr(s, b->cap, b->nq, dst_ref), tt,
+                    colset(s, first, stride, count, qfirst, nq), s.hbuf + slot, s.nloc, s.partials, s.g_vec, ctl);
+    }
+    if (want_norm) {
+      ProfScope ps(c, EIGENEX_K_SMALL, 0.0);
+      launch_reduce(c->stream, s.partials, s.pstride, s.g_vec, 1, s.hbuf + b->slot_nrm(), ctl);
+    }
+  }
+  return want_norm ? allreduce(b, b->slot_nrm(), 1) : 0;
+}
+
+// Gram-Schmidt of the vector in src against the selected columns, result in dst,
+// ||dst||^2 in hbuf[slot_nrm].  Batched: one dots pass + one update pass.
+// Sequential: the reference's order, one vector at a time; q_first: orthogonalizing
+// vectors before the basis vectors (Arnoldi, arnoldi.hpp:373-383) or after (Lanczos,
+// lanczos.hpp:416-425).
+int enq_orthogonalize(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_term, int k, int first, int stride,
+                      int count, int nq, bool q_first) {
+  if (b->ortho_mode == EIGENEX_ORTHO_BATCHED) {
+    CHK(enq_dots(b, src_ref, three_term, k, first, stride, count, 0, nq, 0, true));
+    return enq_update(b, src_ref, dst_ref, three_term, k, first, stride, count, 0, nq, 0, true, true);
+  }
+  // sequential modified Gram-Schmidt
+  const int total = count + nq;
+  CHK(enq_update(b, src_ref, dst_ref, three_term, k, 0, 1, 0, 0, 0, 0, total == 0, true));
+  int done = 0;
+  auto one_q = [&](int q) -> int {
+    const int slot = count + q;
+    CHK(enq_dots(b, dst_ref, false, 0, 0, 1, 0, q, 1, slot, true));
+    ++done;
+    return enq_update(b, dst_ref, dst_ref, false, 0, 0, 1, 0, q, 1, slot, done == total, true);
+  };
+  auto one_v = [&](int i) -> int {
+    const int slot = i;
+    CHK(enq_dots(b, dst_ref, false, 0, first + i * stride, 1, 1, 0, 0, slot, true));
+    ++done;
+    return enq_update(b, dst_ref, dst_ref, false, 0, first + i * stride, 1, 1, 0, 0, slot, done == total, true);
+  };
+  if (q_first)
+    for (int q = 0; q < nq; ++q) CHK(one_q(q));
+  for (int i = 0; i < count; ++i) CHK(one_v(i));
+  if (!q_first)
+    for (int q = 0; q < nq; ++q) CHK(one_q(q));
+  return 0;
+}
+
+// v = (A + shift) * (w*scale), basis column `ucol` = w*scale, optional alpha = u.v -> hbuf[slot_alpha]
+// Returns 1 in *skipped if the device had already stopped (host-operator path only).
+int enq_apply(eigenex_basis_s* b, int ucol, bool want_dot) {
+  eigenex_context_s* c = b->ctx;
+  if (b->csr) {
+    CHK(halo_exchange(b));
+    for (auto& s : b->sh) {
+      CsrShard* m = s.csr;
+      {
+        ProfScope ps(c, EIGENEX_K_SPMV, 12.0 * m->nnz + 4.0 * (m->nloc + 1) + 32.0 * m->nloc + (want_dot ? 16.0 * m->nloc : 0.0));
+        launch_spmv(c->stream, m->rowptr, m->col, m->val, s.w, &s.ctrl->scale, b->shift, s.v,
+                    s.V + (int64_t)ucol * s.ldv, s.nloc, want_dot ? s.partials : nullptr, s.g_spmv, s.ctrl);
+      }
+      if (want_dot) {
+        ProfScope ps(c, EIGENEX_K_SMALL, 0.0);
+        launch_reduce(c->stream, s.partials, s.pstride, s.g_spmv, 1, s.hbuf + b->slot_alpha(), s.ctrl);
+      }
+    }
+    return want_dot ? allreduce(b, b->slot_alpha(), 1) : 0;
+  }
+  // operator lives in host code (MatMulFunction, lanczos.hpp:116): stage through pinned memory
+  if (!b->fn) return fail(EIGENEX_ERR_STATE, "no operator: neither a CSR handle nor a host callback is set");
+  BasisShard& s = b->sh[0];
+  double* u = s.V + (int64_t)ucol * s.ldv;
+  launch_scale(c->stream, s.w, &s.ctrl->scale, 1.0, u, s.nloc, s.ctrl);
+  HIPCHK(hipMemcpyAsync(b->pin_in, u, sizeof(double) * s.nloc, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(b->pin_ctrl, s.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (b->pin_ctrl->stopped) return 0;  // the reference would not have called the operator
+  b->fn(b->pin_in, b->pin_out, b->fn_user);
+  HIPCHK(hipMemcpyAsync(s.v, b->pin_out, sizeof(double) * s.nloc, hipMemcpyHostToDevice, c->stream));
+  if (want_dot || b->shift != 0.0) {
+    launch_shift_dot(c->stream, s.v, u, b->shift, s.nloc, s.partials, s.g_vec, s.ctrl);
+    launch_reduce(c->stream, s.partials, s.pstride, s.g_vec, 1, s.hbuf + b->slot_alpha(), s.ctrl);
+  }
+  return 0;
+}
+
+// setInitialLanczosvector / setInitialArnoldivector (lanczos.hpp:299-323, arnoldi.hpp:245-269):
+// the start vector sits in W; deflate by orthogonalizingVectors_, norm, fail or scale = 1/norm.
+int enq_initial_vector(eigenex_basis_s* b) {
+  CHK(enq_orthogonalize(b, EIGENEX_VEC_W, EIGENEX_VEC_W, false, 0, 0, 1, 0, b->nq, true));
+  for (auto& s : b->sh)
+    launch_fin_norm(b->ctx->stream, s.ctrl, s.hbuf + b->slot_nrm(), b->threshold, kFinInit, s.beta);
+  return 0;
+}
+
+// one call of LanczosBase::updateLanczosSteps()  (lanczos.hpp:371-457)
+int lanczos_call(eigenex_basis_s* b) {
+  hipStream_t st = b->ctx->stream;
+  if (!b->started) {
+    b->started = true;
+    CHK(enq_initial_vector(b));
+    CHK(enq_apply(b, 0, true));  // :389-392
+    for (auto& s : b->sh) launch_fin_alpha(st, s.ctrl, s.hbuf + b->slot_alpha(), s.alpha, 1, b->cap);  // :395
+    b->h_nvec = 1;
+    return 0;
+  }
+  const int k = b->h_nvec - 1;
+  if (b->h_nvec >= b->cap) return fail(EIGENEX_ERR_STATE, "basis capacity exhausted");
+  // columns to re-orthogonalise against  (:411-426)
+  int first = 0, stride = 1, count = 0, nq = 0;
+  if (b->interval > 0) {
+    const int64_t nk = k + 2;  // lanczosvectors_.size() after the push_back
+    const int64_t kmod = (nk - 1) % b->interval;
+    first = (int)kmod;
+    stride = (int)std::min<int64_t>(b->interval, 1 << 30);
+    count = kmod < nk - 1 ? (int)((nk - 1 - kmod + b->interval - 1) / b->interval) : 0;
+    nq = kmod == 0 ? b->nq : 0;
+  }
+  CHK(enq_orthogonalize(b, EIGENEX_VEC_V, EIGENEX_VEC_W, true, k, first, stride, count, nq, false));
+  for (auto& s : b->sh) launch_fin_norm(st, s.ctrl, s.hbuf + b->slot_nrm(), b->threshold, kFinLanczos, s.beta);  // :429-437
+  CHK(enq_apply(b, k + 1, true));  // :439-445
+  for (auto& s : b->sh) launch_fin_alpha(st, s.ctrl, s.hbuf + b->slot_alpha(), s.alpha, 0, b->cap);  // :448-450
+  b->h_nvec++;
+  return 0;
+}
+
+// one call of ArnoldiBase::updateArnoldiSteps()  (arnoldi.hpp:312-392)
+int arnoldi_call(eigenex_basis_s* b) {
+  hipStream_t st = b->ctx->stream;
+  int k;
+  if (!b->started) {
+    b->started = true;
+    CHK(enq_initial_vector(b));
+    k = 0;
+  } else {
+    k = b->h_nvec;
+    if (k >= b->cap && (int64_t)k < b->n_global) return fail(EIGENEX_ERR_STATE, "basis capacity exhausted");
+    for (auto& s : b->sh) launch_arnoldi_begin(st, s.ctrl, b->threshold, b->n_global, b->cap, s.H, b->ldh);  // :357-365
+    if (k >= b->cap) return 0;  // full Krylov space: the begin kernel has recorded "returned false"
+  }
+  CHK(enq_apply(b, k, false));  // :333-336, :369-372
+  if (!b->csr && b->shift != 0.0) { /* shift applied inside enq_apply's host path */ }
+  // :337-345, :373-383
+  CHK(enq_orthogonalize(b, EIGENEX_VEC_V, EIGENEX_VEC_W, false, 0, 0, 1, k + 1, b->nq, true));
+  for (auto& s : b->sh) {
+    launch_fin_norm(st, s.ctrl, s.hbuf + b->slot_nrm(), b->threshold, kFinArnoldi, s.beta);  // :348, :385
+    launch_arnoldi_end(st, s.ctrl, s.hbuf, s.H, b->ldh);
+  }
+  b->h_nvec = k + 1;
+  return 0;
+}
+
+int sync_ctrl(eigenex_basis_s* b, Ctrl* out) {
+  eigenex_context_s* c = b->ctx;
+  HIPCHK(hipMemcpyAsync(b->pin_ctrl, b->sh[0].ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *out = *b->pin_ctrl;
+  b->h_nvec = out->nvec;
+  return 0;
+}
+
+void fill_state(const Ctrl& ct, eigenex_state_t* st) {
+  if (!st) return;
+  st->nvec = ct.nvec;
+  st->iterations = ct.iterations;
+  st->nalpha = ct.nalpha;
+  st->nbeta = ct.nbeta;
+  st->stopped = ct.stopped;
+  st->calls_true = ct.calls_true;
+  st->residue = ct.residue;
+}
+
+}  // namespace
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+extern "C" {
+
+int eigenex_version(void) { return EIGENEX_VERSION; }
+const char* eigenex_last_error(void) { return g_err.c_str(); }
+
+int eigenex_device_count(int* count) {
+  if (!count) return fail(EIGENEX_ERR_ARG, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(EIGENEX_ERR_NODEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  }
+  *count = n;
+  return 0;
+}
+
+int eigenex_partition(int64_t n_global, int nshards, int shard, int64_t* begin, int64_t* end) {
+  if (n_global < 0 || nshards <= 0 || shard < 0 || shard >= nshards || !begin || !end)
+    return fail(EIGENEX_ERR_ARG, "eigenex_partition: bad argument");
+  partition(n_global, nshards, shard, begin, end);
+  return 0;
+}
+
+int eigenex_halo_plan(int64_t n_global, int nshards, int shard, int64_t nnz, const int32_t* col_global,
+                      int64_t* n_halo, int32_t* halo_cols, int64_t* count_per_owner) {
+  if (n_global <= 0 || nshards <= 0 || shard < 0 || shard >= nshards || nnz < 0 || !n_halo)
+    return fail(EIGENEX_ERR_ARG, "eigenex_halo_plan: bad argument");
+  int64_t rb, re;
+  partition(n_global, nshards, shard, &rb, &re);
+  std::vector<int32_t> rem;
+  for (int64_t p = 0; p < nnz; ++p) {
+    const int64_t c = col_global[p];
+    if (c < 0 || c >= n_global) return fail(EIGENEX_ERR_ARG, "column index out of range");
+    if (c < rb || c >= re) rem.push_back((int32_t)c);
+  }
+  std::sort(rem.begin(), rem.end());
+  rem.erase(std::unique(rem.begin(), rem.end()), rem.end());
+  *n_halo = (int64_t)rem.size();
+  if (halo_cols) std::copy(rem.begin(), rem.end(), halo_cols);
+  if (count_per_owner) {
+    for (int o = 0; o < nshards; ++o) count_per_owner[o] = 0;
+    for (int32_t c : rem) count_per_owner[owner_of(n_global, nshards, c)]++;
+  }
+  return 0;
+}
+
+int eigenex_rccl_unique_id(void* id128) {
+  if (!id128) return fail(EIGENEX_ERR_ARG, "id128 is NULL");
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId must be 128 bytes");
+  ncclUniqueId id;
+  NCCLCHK(ncclGetUniqueId(&id));
+  std::memcpy(id128, &id, sizeof(id));
+  return 0;
+}
+
+static int context_common(eigenex_context_s* c, int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(EIGENEX_ERR_NODEVICE, "no HIP device available: this library has no CPU path");
+  if (device < 0 || device >= n) return fail(EIGENEX_ERR_ARG, "device index out of range");
+  c->device = device;
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  set_num_cu(prop.multiProcessorCount);
+  HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  return 0;
+}
+
+int eigenex_context_create(int device, int rank, int world_size, const void* rccl_id128, eigenex_context_t* out) {
+  if (!out || world_size <= 0 || rank < 0 || rank >= world_size) return fail(EIGENEX_ERR_ARG, "bad rank/world_size");
+  if (world_size > 1 && !rccl_id128) return fail(EIGENEX_ERR_ARG, "rccl_id128 is required when world_size > 1");
+  auto* c = new eigenex_context_s();
+  int rc = context_common(c, device);
+  if (rc) {
+    delete c;
+    return rc;
+  }
+  c->rank = rank;
+  c->world = world_size;
+  c->P = world_size;
+  c->local = {rank};
+  if (world_size > 1) {
+    ncclUniqueId id;
+    std::memcpy(&id, rccl_id128, sizeof(id));
+    ncclResult_t r = ncclCommInitRank(&c->comm, world_size, id, rank);
+    if (r != ncclSuccess) {
+      std::string m = std::string("ncclCommInitRank: ") + ncclGetErrorString(r);
+      (void)hipStreamDestroy(c->stream);
+      delete c;
+      return fail(EIGENEX_ERR_RCCL, m);
+    }
+  }
+  *out = c;
+  return 0;
+}
+
+int eigenex_context_create_loopback(int device, int nshards, eigenex_context_t* out) {
+  if (!out || nshards <= 0 || nshards > 64) return fail(EIGENEX_ERR_ARG, "nshards must be in [1, 64]");
+  auto* c = new eigenex_context_s();
+  int rc = context_common(c, device);
+  if (rc) {
+    delete c;
+    return rc;
+  }
+  c->loopback = true;
+  c->P = nshards;
+  for (int s = 0; s < nshards; ++s) c->local.push_back(s);
+  *out = c;
+  return 0;
+}
+
+int eigenex_context_destroy(eigenex_context_t c) {
+  if (!c) return 0;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& p : c->pool) {
+    (void)hipEventDestroy(p.first);
+    (void)hipEventDestroy(p.second);
+  }
+  if (c->comm) (void)ncclCommDestroy(c->comm);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+  return 0;
+}
+
+int eigenex_context_sync(eigenex_context_t c) {
+  if (!c) return fail(EIGENEX_ERR_ARG, "ctx is NULL");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int eigenex_context_info(eigenex_context_t c, int* rank, int* world_size, int* nshards_total, int* nshards_local) {
+  if (!c) return fail(EIGENEX_ERR_ARG, "ctx is NULL");
+  if (rank) *rank = c->rank;
+  if (world_size) *world_size = c->world;
+  if (nshards_total) *nshards_total = c->P;
+  if (nshards_local) *nshards_local = (int)c->local.size();
+  return 0;
+}
+
+void* eigenex_context_stream(eigenex_context_t c) { return c ? (void*)c->stream : nullptr; }
+
+int eigenex_profile_enable(eigenex_context_t c, int on) {
+  if (!c) return fail(EIGENEX_ERR_ARG, "ctx is NULL");
+  if (!on) CHK(prof_collect(c));
+  c->profiling = on != 0;
+  return 0;
+}
+
+int eigenex_profile_reset(eigenex_context_t c) {
+  if (!c) return fail(EIGENEX_ERR_ARG, "ctx is NULL");
+  CHK(prof_collect(c));
+  for (int k = 0; k < EIGENEX_K_COUNT; ++k) c->acc_ms[k] = c->acc_bytes[k] = 0.0, c->acc_n[k] = 0;
+  return 0;
+}
+
+int eigenex_profile_get(eigenex_context_t c, int kind, int64_t* launches, double* total_ms, double* total_bytes) {
+  if (!c || kind < 0 || kind >= EIGENEX_K_COUNT) return fail(EIGENEX_ERR_ARG, "bad profile kind");
+  CHK(prof_collect(c));
+  if (launches) *launches = c->acc_n[kind];
+  if (total_ms) *total_ms = c->acc_ms[kind];
+  if (total_bytes) *total_bytes = c->acc_bytes[kind];
+  return 0;
+}
+
+// ---- operator ---------------------------------------------------------------
+int eigenex_csr_upload(eigenex_context_t c, int64_t n_global, int64_t row_begin, int64_t n_rows, const int32_t* rowptr,
+                       const int32_t* col_global, const double* val, eigenex_csr_t* out) {
+  if (!c || !out || !rowptr || n_global <= 0 || n_rows < 0) return fail(EIGENEX_ERR_ARG, "eigenex_csr_upload: bad argument");
+  if (n_rows > 0 && rowptr[n_rows] > rowptr[0] && (!col_global || !val)) return fail(EIGENEX_ERR_ARG, "col/val is NULL");
+  HIPCHK(hipSetDevice(c->device));
+  int64_t fb, fe, lb, le;
+  partition(n_global, c->P, c->local.front(), &fb, &fe);
+  partition(n_global, c->P, c->local.back(), &lb, &le);
+  if (row_begin != fb || row_begin + n_rows != le)
+    return fail(EIGENEX_ERR_ARG, "rows passed do not match eigenex_partition for this context");
+  auto* m = new eigenex_csr_s();
+  m->ctx = c;
+  m->n_global = n_global;
+  m->sh.resize(c->local.size());
+  int rc = 0;
+  for (size_t i = 0; i < c->local.size() && !rc; ++i) {
+    int64_t rb, re;
+    partition(n_global, c->P, c->local[i], &rb, &re);
+    rc = build_shard_host(c, n_global, c->local[i], rowptr + (rb - row_begin), col_global, val, m->sh[i]);
+  }
+  if (!rc && c->P > 1) rc = c->loopback ? build_send_lists_loopback(c, m) : exchange_send_lists_rccl(c, n_global, m->sh[0]);
+  if (rc) {
+    std::string keep = g_err;
+    eigenex_csr_destroy(m);
+    g_err = keep;
+    return rc;
+  }
+  *out = m;
+  return 0;
+}
+
+int eigenex_csr_laplacian3d(eigenex_context_t c, int64_t n, eigenex_csr_t* out) {
+  if (!c || !out || n < 2 || n > 1290) return fail(EIGENEX_ERR_ARG, "eigenex_csr_laplacian3d: n must be in [2, 1290]");
+  HIPCHK(hipSetDevice(c->device));
+  const int64_t N = n * n * n, n2 = n * n;
+  auto* m = new eigenex_csr_s();
+  m->ctx = c;
+  m->n_global = N;
+  m->sh.resize(c->local.size());
+  auto cleanup = [&](int rc) {
+    std::string keep = g_err;
+    eigenex_csr_destroy(m);
+    g_err = keep;
+    return rc;
+  };
+  auto nnz_before = [&](int64_t i) {
+    const int64_t n3 = N;
+    const int64_t cx0 = (i + n - 1) / n, cx1 = i / n, mm = i % n2;
+    const int64_t cy0 = (i / n2) * n + std::min<int64_t>(mm, n);
+    const int64_t cy1 = (i / n2) * n + std::max<int64_t>(0, mm - (n2 - n));
+    const int64_t cz0 = std::min<int64_t>(i, n2), cz1 = std::max<int64_t>(0, i - (n3 - n2));
+    return 7 * i - (cx0 + cx1 + cy0 + cy1 + cz0 + cz1);
+  };
+  // every shard asks for the n^2 rows below and above its range (a superset of what it reads)
+  auto lower = [&](int64_t rb) { return std::max<int64_t>(0, rb - n2); };
+  auto upper = [&](int64_t re) { return std::min<int64_t>(N, re + n2); };
+  for (size_t i = 0; i < c->local.size(); ++i) {
+    CsrShard& s = m->sh[i];
+    s.gshard = c->local[i];
+    partition(N, c->P, s.gshard, &s.rb, &s.re);
+    s.nloc = s.re - s.rb;
+    s.npad = pad_rows(s.nloc);
+    s.nnz = nnz_before(s.re) - nnz_before(s.rb);
+    if (s.nnz > (int64_t)2147483647 - 16384) return cleanup(fail(EIGENEX_ERR_ARG, "nnz of a shard must be < 2^31 - 16384"));
+    const int64_t lo = lower(s.rb), hi = upper(s.re);
+    const int64_t n_lower = s.rb - lo, n_upper = hi - s.re;
+    s.nhalo = n_lower + n_upper;
+    if (int rc = [&]() -> int {
+          HIPCHK(hipMalloc(&s.rowptr, sizeof(int32_t) * (s.nloc + 1)));
+          HIPCHK(hipMalloc(&s.col, sizeof(int32_t) * (s.nnz + 8)));
+          HIPCHK(hipMalloc(&s.val, sizeof(double) * (s.nnz + 8)));
+          HIPCHK(hipMemsetAsync(s.col + s.nnz, 0, sizeof(int32_t) * 8, c->stream));
+          HIPCHK(hipMemsetAsync(s.val + s.nnz, 0, sizeof(double) * 8, c->stream));
+          return 0;
+        }())
+      return cleanup(rc);
+    launch_laplacian3d(c->stream, n, s.rb, s.re, lo, n_lower, s.npad, s.rowptr, s.col, s.val);
+    // recv segments: [lo, rb) then [re, hi), split by owner
+    auto add_range = [&](int64_t a, int64_t bnd, int64_t hoff) {
+      int64_t p = a;
+      while (p < bnd) {
+        const int o = owner_of(N, c->P, p);
+        int64_t ob, oe;
+        partition(N, c->P, o, &ob, &oe);
+        const int64_t q = std::min(bnd, oe);
+        s.recv.push_back({o, hoff + (p - a), q - p, -1});
+        p = q;
+      }
+    };
+    add_range(lo, s.rb, 0);
+    add_range(s.re, hi, n_lower);
+  }
+  // send segments by symmetry of the stencil: peer p reads [lower(p.rb), p.rb) and [p.re, upper(p.re))
+  if (c->P > 1) {
+    for (auto& s : m->sh) {
+      for (int p = 0; p < c->P; ++p) {
+        if (p == s.gshard) continue;
+        int64_t pb, pe;
+        partition(N, c->P, p, &pb, &pe);
+        const int64_t a1 = std::max(lower(pb), s.rb), b1 = std::min(pb, s.re);
+        const int64_t a2 = std::max(pe, s.rb), b2 = std::min(upper(pe), s.re);
+        if (b1 > a1 && b2 > a2) return cleanup(fail(EIGENEX_ERR_STATE, "laplacian halo: two segments for one peer"));
+        if (b1 > a1) s.send.push_back({p, 0, b1 - a1, a1 - s.rb});
+        if (b2 > a2) s.send.push_back({p, 0, b2 - a2, a2 - s.rb});
+      }
+    }
+  }
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return cleanup(fail(EIGENEX_ERR_HIP, "laplacian generator failed"));
+  *out = m;
+  return 0;
+}
+
+int eigenex_csr_destroy(eigenex_csr_t m) {
+  if (!m) return 0;
+  (void)hipSetDevice(m->ctx->device);
+  (void)hipStreamSynchronize(m->ctx->stream);
+  for (auto& s : m->sh) free_csr_shard(s);
+  delete m;
+  return 0;
+}
+
+int eigenex_csr_info(eigenex_csr_t m, int64_t* n_global, int64_t* n_local, int64_t* nnz_local, int64_t* n_halo_local) {
+  if (!m) return fail(EIGENEX_ERR_ARG, "csr is NULL");
+  int64_t nl = 0, nz = 0, nh = 0;
+  for (auto& s : m->sh) nl += s.nloc, nz += s.nnz, nh += s.nhalo;
+  if (n_global) *n_global = m->n_global;
+  if (n_local) *n_local = nl;
+  if (nnz_local) *nnz_local = nz;
+  if (n_halo_local) *n_halo_local = nh;
+  return 0;
+}
+
+// ---- Krylov state -------------------------------------------------------------
+int eigenex_basis_destroy(eigenex_basis_t b) {
+  if (!b) return 0;
+  (void)hipSetDevice(b->ctx->device);
+  (void)hipStreamSynchronize(b->ctx->stream);
+  for (auto& s : b->sh) {
+    for (void* p : {(void*)s.V, (void*)s.Q, (void*)s.v, (void*)s.w, (void*)s.partials, (void*)s.hbuf, (void*)s.alpha,
+                    (void*)s.beta, (void*)s.H, (void*)s.X, (void*)s.ctrl, (void*)s.ctrl_zero})
+      if (p) (void)hipFree(p);
+  }
+  if (b->pin_in) (void)hipHostFree(b->pin_in);
+  if (b->pin_out) (void)hipHostFree(b->pin_out);
+  if (b->pin_ctrl) (void)hipHostFree(b->pin_ctrl);
+  delete b;
+  return 0;
+}
+
+int eigenex_basis_create(eigenex_context_t c, eigenex_csr_t csr, int64_t n_global, int capacity, int n_ortho,
+                         eigenex_basis_t* out) {
+  if (!c || !out || n_global <= 0 || capacity < 1 || n_ortho < 0) return fail(EIGENEX_ERR_ARG, "eigenex_basis_create: bad argument");
+  if (csr && (csr->ctx != c || csr->n_global != n_global)) return fail(EIGENEX_ERR_ARG, "csr belongs to another context or has another size");
+  if (!csr && c->P != 1) return fail(EIGENEX_ERR_ARG, "a host-callback operator needs a single-shard context");
+  HIPCHK(hipSetDevice(c->device));
+  auto* b = new eigenex_basis_s();
+  b->ctx = c;
+  b->csr = csr;
+  b->n_global = n_global;
+  b->cap = capacity;
+  b->nq = n_ortho;
+  b->maxcols = capacity + n_ortho;
+  b->ldh = capacity + 2;
+  b->sh.resize(c->local.size());
+  auto body = [&]() -> int {
+    for (size_t i = 0; i < c->local.size(); ++i) {
+      BasisShard& s = b->sh[i];
+      s.gshard = c->local[i];
+      int64_t rb, re;
+      partition(n_global, c->P, s.gshard, &rb, &re);
+      s.rb = rb;
+      s.nloc = re - rb;
+      s.ldv = pad_rows(s.nloc);
+      if (s.ldv == 0) s.ldv = 64;
+      s.csr = csr ? &csr->sh[i] : nullptr;
+      s.nhalo = s.csr ? s.csr->nhalo : 0;
+      const size_t vbytes = sizeof(double) * (size_t)s.ldv;
+      HIPCHK(hipMalloc(&s.V, vbytes * capacity));
+      HIPCHK(hipMemsetAsync(s.V, 0, vbytes * capacity, c->stream));
+      if (n_ortho) {
+        HIPCHK(hipMalloc(&s.Q, vbytes * n_ortho));
+        HIPCHK(hipMemsetAsync(s.Q, 0, vbytes * n_ortho, c->stream));
+      }
+      HIPCHK(hipMalloc(&s.v, vbytes));
+      HIPCHK(hipMemsetAsync(s.v, 0, vbytes, c->stream));
+      HIPCHK(hipMalloc(&s.w, sizeof(double) * (size_t)(s.ldv + s.nhalo + 8)));
+      HIPCHK(hipMemsetAsync(s.w, 0, sizeof(double) * (size_t)(s.ldv + s.nhalo + 8), c->stream));
+      s.g_vec = grid_for_tiles((s.nloc + kTileRows - 1) / kTileRows, 4);
+      s.g_spmv = grid_for_tiles((s.nloc + kSpmvRows - 1) / kSpmvRows, 8);
+      s.pstride = std::max(s.g_vec, s.g_spmv);
+      const int rows = std::max(b->maxcols, 8) + 4;
+      HIPCHK(hipMalloc(&s.partials, sizeof(double) * (size_t)s.pstride * rows));
+      HIPCHK(hipMalloc(&s.hbuf, sizeof(double) * (b->maxcols + 40)));
+      HIPCHK(hipMemsetAsync(s.hbuf, 0, sizeof(double) * (b->maxcols + 40), c->stream));
+      HIPCHK(hipMalloc(&s.alpha, sizeof(double) * (capacity + 2)));
+      HIPCHK(hipMalloc(&s.beta, sizeof(double) * (capacity + 2)));
+      HIPCHK(hipMemsetAsync(s.alpha, 0, sizeof(double) * (capacity + 2), c->stream));
+      HIPCHK(hipMemsetAsync(s.beta, 0, sizeof(double) * (capacity + 2), c->stream));
+      HIPCHK(hipMalloc(&s.H, sizeof(double) * (size_t)b->ldh * (capacity + 1)));
+      HIPCHK(hipMemsetAsync(s.H, 0, sizeof(double) * (size_t)b->ldh * (capacity + 1), c->stream));
+      HIPCHK(hipMalloc(&s.ctrl, sizeof(Ctrl)));
+      HIPCHK(hipMalloc(&s.ctrl_zero, sizeof(Ctrl)));
+      HIPCHK(hipMemsetAsync(s.ctrl, 0, sizeof(Ctrl), c->stream));
+      HIPCHK(hipMemsetAsync(s.ctrl_zero, 0, sizeof(Ctrl), c->stream));
+    }
+    HIPCHK(hipHostMalloc(&b->pin_ctrl, sizeof(Ctrl)));
+    if (!csr) {
+      HIPCHK(hipHostMalloc(&b->pin_in, sizeof(double) * (size_t)b->sh[0].ldv));
+      HIPCHK(hipHostMalloc(&b->pin_out, sizeof(double) * (size_t)b->sh[0].ldv));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+  };
+  int rc = body();
+  if (rc) {
+    std::string keep = g_err;
+    eigenex_basis_destroy(b);
+    g_err = keep;
+    return rc;
+  }
+  *out = b;
+  return 0;
+}
+
+int eigenex_basis_set_host_operator(eigenex_basis_t b, eigenex_matvec_fn fn, void* user) {
+  if (!b) return fail(EIGENEX_ERR_ARG, "basis is NULL");
+  if (b->csr) return fail(EIGENEX_ERR_STATE, "this basis was created for a device CSR operator");
+  b->fn = fn;
+  b->fn_user = user;
+  return 0;
+}
+
+int eigenex_basis_configure(eigenex_basis_t b, double eigenvalue_shift, double threshold, int64_t interval, int ortho_mode) {
+  if (!b) return fail(EIGENEX_ERR_ARG, "basis is NULL");
+  if (ortho_mode != EIGENEX_ORTHO_BATCHED && ortho_mode != EIGENEX_ORTHO_SEQUENTIAL) return fail(EIGENEX_ERR_ARG, "bad ortho_mode");
+  b->shift = eigenvalue_shift;
+  b->threshold = threshold;
+  b->interval = interval;
+  b->ortho_mode = ortho_mode;
+  return 0;
+}
+
+int eigenex_basis_clear(eigenex_basis_t b) {
+  if (!b) return fail(EIGENEX_ERR_ARG, "basis is NULL");
+  HIPCHK(hipSetDevice(b->ctx->device));
+  for (auto& s : b->sh) HIPCHK(hipMemsetAsync(s.ctrl, 0, sizeof(Ctrl), b->ctx->stream));
+  b->started = false;
+  b->h_nvec = 0;
+  return 0;
+}
+
+static int vec_copy(eigenex_basis_t b, int ref, double* host, bool up) {
+  if (!b || !host) return fail(EIGENEX_ERR_ARG, "NULL argument");
+  eigenex_context_s* c = b->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  const int64_t rb0 = b->sh[0].rb;
+  for (auto& s : b->sh) {
+    double* d = vec_ptr(s, b->cap, b->nq, ref);
+    if (!d) return fail(EIGENEX_ERR_ARG, "bad vector reference");
+    if (up)
+      HIPCHK(hipMemcpyAsync(d, host + (s.rb - rb0), sizeof(double) * s.nloc, hipMemcpyHostToDevice, c->stream));
+    else
+      HIPCHK(hipMemcpyAsync(host + (s.rb - rb0), d, sizeof(double) * s.nloc, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int eigenex_vec_upload(eigenex_basis_t b, int ref, const double* host) { return vec_copy(b, ref, const_cast<double*>(host), true); }
+int eigenex_vec_download(eigenex_basis_t b, int ref, double* host) { return vec_copy(b, ref, host, false); }
+
+// ---- step primitives -------------------------------------------------------------
+static int fetch_h(eigenex_basis_t b, int off, int n, double* host) {
+  if (!host || n <= 0) return 0;
+  HIPCHK(hipMemcpyAsync(host, b->sh[0].hbuf + off, sizeof(double) * n, hipMemcpyDeviceToHost, b->ctx->stream));
+  HIPCHK(hipStreamSynchronize(b->ctx->stream));
+  return 0;
+}
+
+static int push_h(eigenex_basis_t b, int off, int n, const double* host) {
+  for (auto& s : b->sh) HIPCHK(hipMemcpyAsync(s.hbuf + off, host, sizeof(double) * n, hipMemcpyHostToDevice, b->ctx->stream));
+  HIPCHK(hipStreamSynchronize(b->ctx->stream));  // host buffer may be pageable / reused
+  return 0;
+}
+
+static bool cols_ok(eigenex_basis_t b, int first, int stride, int count, int nq) {
+  if (count < 0 || nq < 0 || nq > b->nq || count + nq > b->maxcols) return false;
+  if (count == 0) return true;
+  if (first < 0 || stride < 1) return false;
+  return (int64_t)first + (int64_t)(count - 1) * stride < b->cap;
+}
+
+int eigenex_apply(eigenex_basis_t b, int x_ref, int y_ref, double shift, double* dot) {
+  if (!b || !b->csr) return fail(EIGENEX_ERR_ARG, "eigenex_apply needs a basis with a device CSR operator");
+  if (y_ref == EIGENEX_VEC_W) return fail(EIGENEX_ERR_ARG, "y may not be the operator input vector");
+  eigenex_context_s* c = b->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  for (auto& s : b->sh) {
+    double* x = vec_ptr(s, b->cap, b->nq, x_ref);
+    double* y = vec_ptr(s, b->cap, b->nq, y_ref);
+    if (!x || !y || x == y) return fail(EIGENEX_ERR_ARG, "bad vector reference");
+    if (x != s.w) HIPCHK(hipMemcpyAsync(s.w, x, sizeof(double) * s.nloc, hipMemcpyDeviceToDevice, c->stream));
+  }
+  CHK(halo_exchange(b, false));
+  for (auto& s : b->sh) {
+    CsrShard* m = s.csr;
+    ProfScope ps(c, EIGENEX_K_SPMV, 12.0 * m->nnz + 4.0 * (m->nloc + 1) + 16.0 * m->nloc);
+    launch_spmv(c->stream, m->rowptr, m->col, m->val, s.w, nullptr, shift, vec_ptr(s, b->cap, b->nq, y_ref), nullptr,
+                s.nloc, dot ? s.partials : nullptr, s.g_spmv, s.ctrl_zero);
+    if (dot) launch_reduce(c->stream, s.partials, s.pstride, s.g_spmv, 1, s.hbuf + b->slot_alpha(), s.ctrl_zero);
+  }
+  if (dot) {
+    CHK(allreduce(b, b->slot_alpha(), 1));
+    return fetch_h(b, b->slot_alpha(), 1, dot);
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int eigenex_dots(eigenex_basis_t b, int w_ref, int first, int stride, int count, int n_ortho_used, double* h) {
+  if (!b || !h) return fail(EIGENEX_ERR_ARG, "NULL argument");
+  if (!cols_ok(b, first, stride, count, n_ortho_used)) return fail(EIGENEX_ERR_ARG, "bad column selection");
+  if (!vec_ptr(b->sh[0], b->cap, b->nq, w_ref)) return fail(EIGENEX_ERR_ARG, "bad vector reference");
+  HIPCHK(hipSetDevice(b->ctx->device));
+  CHK(enq_dots(b, w_ref, false, 0, first, stride, count, 0, n_ortho_used, 0, false));
+  return fetch_h(b, 0, count + n_ortho_used, h);
+}
+
+int eigenex_update(eigenex_basis_t b, int w_ref, int first, int stride, int count, int n_ortho_used, const double* h,
+                   double* nrm2) {
+  if (!b) return fail(EIGENEX_ERR_ARG, "NULL argument");
+  if (!cols_ok(b, first, stride, count, n_ortho_used)) return fail(EIGENEX_ERR_ARG, "bad column selection");
+  if (count + n_ortho_used > 0 && !h) return fail(EIGENEX_ERR_ARG, "h is NULL");
+  if (!vec_ptr(b->sh[0], b->cap, b->nq, w_ref)) return fail(EIGENEX_ERR_ARG, "bad vector reference");
+  HIPCHK(hipSetDevice(b->ctx->device));
+  if (count + n_ortho_used > 0) CHK(push_h(b, 0, count + n_ortho_used, h));
+  CHK(enq_update(b, w_ref, w_ref, false, 0, first, stride, count, 0, n_ortho_used, 0, true, false));
+  if (nrm2) return fetch_h(b, b->slot_nrm(), 1, nrm2);
+  HIPCHK(hipStreamSynchronize(b->ctx->stream));
+  return 0;
+}
+
+int eigenex_axpy2(eigenex_basis_t b, int z_ref, int x_ref, double a, int p_ref, double bcoef, int q_ref) {
+  if (!b) return fail(EIGENEX_ERR_ARG, "NULL argument");
+  eigenex_context_s* c = b->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  const double ab[2] = {a, bcoef};
+  CHK(push_h(b, b->slot_a(), 2, ab));
+  for (auto& s : b->sh) {
+    double *z = vec_ptr(s, b->cap, b->nq, z_ref), *x = vec_ptr(s, b->cap, b->nq, x_ref);
+    double *p = vec_ptr(s, b->cap, b->nq, p_ref), *q = vec_ptr(s, b->cap, b->nq, q_ref);
+    if (!z || !x || !p || !q) return fail(EIGENEX_ERR_ARG, "bad vector reference");
+    ThreeTerm tt{p, bcoef != 0.0 ? q : nullptr, s.hbuf + b->slot_a(), s.hbuf + b->slot_b()};
+    ProfScope ps(c, EIGENEX_K_UPDATE, 32.0 * s.nloc);
+    launch_update(c->stream, x, z, tt, colset(s, 0, 1, 0, 0, 0), s.hbuf, s.nloc, s.partials, s.g_vec, s.ctrl_zero);
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int eigenex_scale(eigenex_basis_t b, int dst_ref, int src_ref, double sc) {
+  if (!b) return fail(EIGENEX_ERR_ARG, "NULL argument");
+  eigenex_context_s* c = b->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  for (auto& s : b->sh) {
+    double *d = vec_ptr(s, b->cap, b->nq, dst_ref), *x = vec_ptr(s, b->cap, b->nq, src_ref);
+    if (!d || !x) return fail(EIGENEX_ERR_ARG, "bad vector reference");
+    launch_scale(c->stream, x, nullptr, sc, d, s.nloc, s.ctrl_zero);
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ---- fused steps ---------------------------------------------------------------------
+int eigenex_lanczos_enqueue(eigenex_basis_t b, int ncalls) {
+  if (!b || ncalls < 0) return fail(EIGENEX_ERR_ARG, "bad argument");
+  HIPCHK(hipSetDevice(b->ctx->device));
+  for (int i = 0; i < ncalls; ++i) CHK(lanczos_call(b));
+  return 0;
+}
+
+int eigenex_arnoldi_enqueue(eigenex_basis_t b, int ncalls) {
+  if (!b || ncalls < 0) return fail(EIGENEX_ERR_ARG, "bad argument");
+  HIPCHK(hipSetDevice(b->ctx->device));
+  for (int i = 0; i < ncalls; ++i) CHK(arnoldi_call(b));
+  return 0;
+}
+
+int eigenex_lanczos_state(eigenex_basis_t b, eigenex_state_t* st, double* alpha, double* beta) {
+  if (!b) return fail(EIGENEX_ERR_ARG, "basis is NULL");
+  HIPCHK(hipSetDevice(b->ctx->device));
+  Ctrl ct;
+  CHK(sync_ctrl(b, &ct));
+  fill_state(ct, st);
+  hipStream_t s = b->ctx->stream;
+  if (alpha && ct.nalpha) HIPCHK(hipMemcpyAsync(alpha, b->sh[0].alpha, sizeof(double) * ct.nalpha, hipMemcpyDeviceToHost, s));
+  if (beta && ct.nbeta) HIPCHK(hipMemcpyAsync(beta, b->sh[0].beta, sizeof(double) * ct.nbeta, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return 0;
+}
+
+int eigenex_arnoldi_state(eigenex_basis_t b, eigenex_state_t* st, double* hess, int ldh) {
+  if (!b) return fail(EIGENEX_ERR_ARG, "basis is NULL");
+  HIPCHK(hipSetDevice(b->ctx->device));
+  Ctrl ct;
+  CHK(sync_ctrl(b, &ct));
+  fill_state(ct, st);
+  if (hess && ct.nalpha) {
+    if (ldh < ct.nalpha + 1) return fail(EIGENEX_ERR_ARG, "ldh too small");
+    HIPCHK(hipMemcpy2DAsync(hess, sizeof(double) * ldh, b->sh[0].H, sizeof(double) * b->ldh, sizeof(double) * (ct.nalpha + 1),
+                            ct.nalpha, hipMemcpyDeviceToHost, b->ctx->stream));
+    HIPCHK(hipStreamSynchronize(b->ctx->stream));
+  }
+  return 0;
+}
+
+// Ritz vectors (lanczos.hpp:798-816; arnoldi.hpp:841-865 for real S)
+int eigenex_ritz_vectors(eigenex_basis_t b, int nvec, int nev, const double* S, int lds, double* X, int64_t ldx) {
+  if (!b || nvec < 0 || nvec > b->cap || nev < 0 || (nev && (!S || !X)) || lds < nvec) return fail(EIGENEX_ERR_ARG, "eigenex_ritz_vectors: bad argument");
+  eigenex_context_s* c = b->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  int64_t nrows = 0;
+  for (auto& s : b->sh) nrows += s.nloc;
+  if (nev && ldx < nrows) return fail(EIGENEX_ERR_ARG, "ldx too small");
+  const int E = 8;
+  double* d_S = nullptr;
+  HIPCHK(hipMalloc(&d_S, sizeof(double) * (size_t)std::max(nvec, 1) * E));
+  std::vector<double> hostbuf((size_t)4 * E * b->sh.size());
+  int rc = [&]() -> int {
+    for (auto& s : b->sh)
+      if (!s.X) HIPCHK(hipMalloc(&s.X, sizeof(double) * (size_t)s.ldv * E));
+    for (int e0 = 0; e0 < nev; e0 += E) {
+      const int ne = std::min(E, nev - e0);
+      for (int e = 0; e < ne; ++e)
+        HIPCHK(hipMemcpyAsync(d_S + (size_t)e * nvec, S + (size_t)(e0 + e) * lds, sizeof(double) * nvec, hipMemcpyHostToDevice, c->stream));
+      for (auto& s : b->sh) {
+        {
+          ProfScope ps(c, EIGENEX_K_RITZ, 8.0 * s.nloc * nvec + 8.0 * s.nloc * ne);
+          launch_ritz(c->stream, s.V, s.ldv, nvec, d_S, nvec, ne, s.X, s.ldv, s.nloc, s.partials, s.pstride, s.g_vec);
+        }
+        launch_reduce(c->stream, s.partials, s.pstride, s.g_vec, ne, s.hbuf, s.ctrl_zero);
+      }
+      CHK(allreduce(b, 0, ne));  // hbuf[0..ne) = ||x_e||^2
+      // first non-zero entry over the whole (sharded) column
+      for (auto& s : b->sh) launch_first_nonzero(c->stream, s.X, s.ldv, ne, s.nloc, s.hbuf + E);
+      std::vector<double> idxval((size_t)2 * E * c->P, 0.0);
+      if (c->loopback || c->P == 1) {
+        for (size_t i = 0; i < b->sh.size(); ++i)
+          HIPCHK(hipMemcpyAsync(idxval.data() + 2 * E * i, b->sh[i].hbuf + E, sizeof(double) * 2 * ne, hipMemcpyDeviceToHost, c->stream));
+      } else {
+        double* tmp = nullptr;
+        HIPCHK(hipMalloc(&tmp, sizeof(double) * 2 * E * c->P));
+        NCCLCHK(ncclAllGather(b->sh[0].hbuf + E, tmp, (size_t)2 * E, ncclDouble, c->comm, c->stream));
+        HIPCHK(hipMemcpyAsync(idxval.data(), tmp, sizeof(double) * 2 * E * c->P, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        (void)hipFree(tmp);
+      }
+      std::vector<double> nrm2(E, 0.0);
+      HIPCHK(hipMemcpyAsync(nrm2.data(), b->sh[0].hbuf, sizeof(double) * ne, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      std::vector<double> factors(E, 1.0);
+      for (int e = 0; e < ne; ++e) {
+        double phase = 1.0;
+        for (int p = 0; p < c->P; ++p) {  // shards in row order: the first one with a hit wins
+          int64_t pb, pe;
+          partition(b->n_global, c->P, p, &pb, &pe);
+          const double idx = idxval[(size_t)2 * E * p + 2 * e];
+          if (idx < (double)(pe - pb)) {
+            const double v = idxval[(size_t)2 * E * p + 2 * e + 1];
+            phase = v / std::fabs(v);  // lanczos.hpp:809-813
+            break;
+          }
+        }
+        const double nrm = std::sqrt(nrm2[e]);
+        factors[e] = (nrm > 0.0 ? 1.0 / nrm : 1.0) * (1.0 / phase);  // :816
+      }
+      for (auto& s : b->sh) {
+        HIPCHK(hipMemcpyAsync(s.hbuf, factors.data(), sizeof(double) * ne, hipMemcpyHostToDevice, c->stream));
+        launch_scale_columns(c->stream, s.X, s.ldv, ne, s.nloc, s.hbuf);
+        for (int e = 0; e < ne; ++e)
+          HIPCHK(hipMemcpyAsync(X + (size_t)(e0 + e) * ldx + (s.rb - b->sh[0].rb), s.X + (size_t)e * s.ldv, sizeof(double) * s.nloc, hipMemcpyDeviceToHost, c->stream));
+      }
+      HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+  }();
+  (void)hipFree(d_S);
+  return rc;
+}
+
+}  // extern "C"

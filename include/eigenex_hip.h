@@ -1,0 +1,189 @@
+/* eigenex_hip.h -- C ABI of the MI355X (gfx950) Krylov step library.
+ *
+ * This is the drop-in boundary for the hot path of versmc/cmpt-eigenex: the
+ * vector work that LanczosBase::updateLanczosSteps() (reference
+ * include/cmpt/eigen_ex/lanczos.hpp:371-457) and ArnoldiBase::updateArnoldiSteps()
+ * (include/cmpt/eigen_ex/arnoldi.hpp:312-392) perform through Eigen on host
+ * vectors, plus a CSR realisation of the operator callback
+ * (MatMulFunction, lanczos.hpp:116).  The header-only C++ solver classes in
+ * cmpt-eigenex_amd/include/cmpt/eigen_ex/ call ONLY these entry points; a
+ * reference maintainer would bind the same symbols.
+ *
+ * Conventions
+ *   - plain C, opaque handles, no C++/torch types; every function returns an
+ *     int status: 0 = ok, negative = error (eigenex_last_error() has the text).
+ *   - all data are real fp64; indices int32 (per-shard nnz < 2^31); sizes int64.
+ *   - a context owns ONE HIP stream; every call on its handles is ordered on
+ *     that stream.  Calls that return scalars/vectors to the host synchronise;
+ *     the *_enqueue calls do not.
+ *   - rows of the operator and of every Krylov vector are partitioned 1-D into
+ *     contiguous shards (eigenex_partition).  A context created with
+ *     eigenex_context_create owns one shard per process (RCCL over xGMI between
+ *     processes); eigenex_context_create_loopback owns all shards of a
+ *     partition in one process on one device (verification transport: the same
+ *     kernels, halo lists and reduction points, device copies instead of RCCL).
+ *   - host pointers passed to upload/download calls cover the rows this context
+ *     owns: one shard in RCCL mode, all rows in loopback mode.
+ */
+#ifndef EIGENEX_HIP_H
+#define EIGENEX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EIGENEX_VERSION 100
+
+typedef struct eigenex_context_s* eigenex_context_t;
+typedef struct eigenex_csr_s* eigenex_csr_t;     /* device CSR operator (row shards + halo plan) */
+typedef struct eigenex_basis_s* eigenex_basis_t; /* Krylov state: basis slab V, work vectors, coefficients */
+
+/* status codes */
+enum {
+  EIGENEX_OK = 0,
+  EIGENEX_ERR_ARG = -1,     /* invalid argument */
+  EIGENEX_ERR_HIP = -2,     /* HIP runtime error */
+  EIGENEX_ERR_RCCL = -3,    /* RCCL error */
+  EIGENEX_ERR_STATE = -4,   /* call not valid in the current state (e.g. capacity exhausted) */
+  EIGENEX_ERR_NODEVICE = -5 /* no usable GPU */
+};
+
+/* orthogonalisation scheme used by the fused step functions */
+enum {
+  /* batched classical Gram-Schmidt: one pass of dots against all selected basis
+   * vectors, one all-reduce, one update pass (north star: "batched dots + AXPY") */
+  EIGENEX_ORTHO_BATCHED = 0,
+  /* strictly sequential modified Gram-Schmidt, the reference's operation order
+   * (lanczos.hpp:416-418, arnoldi.hpp:380-383): one dot + one axpy per vector */
+  EIGENEX_ORTHO_SEQUENTIAL = 1
+};
+
+/* vector references inside a basis (arguments named *_ref) */
+#define EIGENEX_VEC_COL(c) ((int)(c))        /* basis vector c (lanczosvectors_[c] / arnoldivectors_[c]) */
+#define EIGENEX_VEC_V (-1)                    /* v_: holds A*u (lanczos.hpp:237, arnoldi.hpp:185) */
+#define EIGENEX_VEC_W (-2)                    /* work vector that feeds the operator (with halo space) */
+#define EIGENEX_VEC_ORTHO(q) (-16 - (int)(q)) /* orthogonalizingVectors_[q] (lanczos.hpp:153) */
+
+/* operator callback for operators that live in host code: the reference's
+ * MatMulFunction  std::function<void(const Scalar*, Scalar*)>  (lanczos.hpp:116)
+ * plus a user pointer. `out` must be fully overwritten. */
+typedef void (*eigenex_matvec_fn)(const double* in, double* out, void* user);
+
+/* ---- library ---------------------------------------------------------- */
+int eigenex_version(void);
+const char* eigenex_last_error(void);
+int eigenex_device_count(int* count);
+
+/* rows [*begin, *end) of shard `shard` out of `nshards` for n_global rows */
+int eigenex_partition(int64_t n_global, int nshards, int shard, int64_t* begin, int64_t* end);
+
+/* Halo plan of one row shard, host only (no GPU needed): given the shard's CSR
+ * column indices (GLOBAL numbering) returns the sorted unique remote columns
+ * (halo slot s holds global column halo_cols[s]) and per-owner counts.
+ * Call with halo_cols == NULL to query *n_halo first.  Mirrors what
+ * eigenex_csr_upload does internally; exposed for the CPU (gloo) tests. */
+int eigenex_halo_plan(int64_t n_global, int nshards, int shard, int64_t nnz, const int32_t* col_global,
+                      int64_t* n_halo, int32_t* halo_cols, int64_t* count_per_owner /* nshards */);
+
+/* ---- context ---------------------------------------------------------- */
+/* 128-byte RCCL unique id (rank 0 creates it, the host program broadcasts it). */
+int eigenex_rccl_unique_id(void* id128);
+/* one process per GPU: this process owns shard `rank` of `world_size`. rccl_id may be NULL iff world_size == 1 */
+int eigenex_context_create(int device, int rank, int world_size, const void* rccl_id128, eigenex_context_t* out);
+/* all `nshards` shards in this process on `device` (verification transport) */
+int eigenex_context_create_loopback(int device, int nshards, eigenex_context_t* out);
+int eigenex_context_destroy(eigenex_context_t ctx);
+int eigenex_context_sync(eigenex_context_t ctx);
+int eigenex_context_info(eigenex_context_t ctx, int* rank, int* world_size, int* nshards_total, int* nshards_local);
+/* the context's hipStream_t (as void*) */
+void* eigenex_context_stream(eigenex_context_t ctx);
+
+/* HIP-event timing of every kernel launch (for bench.py's roofline object).
+ * kind: 0 = spmv, 1 = dots, 2 = update, 3 = small (reductions/finalisers), 4 = collectives+copies */
+enum { EIGENEX_K_SPMV = 0, EIGENEX_K_DOTS = 1, EIGENEX_K_UPDATE = 2, EIGENEX_K_SMALL = 3, EIGENEX_K_COMM = 4, EIGENEX_K_RITZ = 5, EIGENEX_K_COUNT = 6 };
+int eigenex_profile_enable(eigenex_context_t ctx, int on);
+int eigenex_profile_reset(eigenex_context_t ctx);
+/* synchronises; launches, summed milliseconds and summed algorithmic bytes of one kind */
+int eigenex_profile_get(eigenex_context_t ctx, int kind, int64_t* launches, double* total_ms, double* total_bytes);
+
+/* ---- operator ---------------------------------------------------------- */
+/* CSR rows owned by this context (RCCL: rows [row_begin, row_begin+n_rows) must equal
+ * eigenex_partition(n_global, world, rank); loopback: row_begin = 0, n_rows = n_global).
+ * rowptr[n_rows+1] is relative to the first passed row, col holds GLOBAL column indices,
+ * ascending within a row is not required.  Host arrays are copied. Collective in RCCL mode.
+ * Replaces the user lambda behind setMatrixMultiplication (lanczos.hpp:179-188). */
+int eigenex_csr_upload(eigenex_context_t ctx, int64_t n_global, int64_t row_begin, int64_t n_rows,
+                       const int32_t* rowptr, const int32_t* col_global, const double* val, eigenex_csr_t* out);
+/* synthetic 7-point Laplacian on an n^3 grid generated on the device (BASELINE configs 2 and 4) */
+int eigenex_csr_laplacian3d(eigenex_context_t ctx, int64_t n, eigenex_csr_t* out);
+int eigenex_csr_destroy(eigenex_csr_t csr);
+int eigenex_csr_info(eigenex_csr_t csr, int64_t* n_global, int64_t* n_local, int64_t* nnz_local, int64_t* n_halo_local);
+
+/* ---- Krylov state ------------------------------------------------------ */
+/* capacity = maximum number of basis vectors (Lanczos with maxIterations m needs m+1,
+ * Arnoldi m: SURVEY F8); n_ortho = size of orthogonalizingVectors_.
+ * csr may be NULL: the operator is then a host callback (single shard only). */
+int eigenex_basis_create(eigenex_context_t ctx, eigenex_csr_t csr, int64_t n_global, int capacity, int n_ortho,
+                         eigenex_basis_t* out);
+int eigenex_basis_destroy(eigenex_basis_t b);
+int eigenex_basis_set_host_operator(eigenex_basis_t b, eigenex_matvec_fn fn, void* user);
+/* settings of LanczosBase/ArnoldiBase that the kernels need (lanczos.hpp:155-159) */
+int eigenex_basis_configure(eigenex_basis_t b, double eigenvalue_shift, double threshold,
+                            int64_t reorthogonalize_interval, int ortho_mode);
+/* clearLanczosSteps()/clearArnoldiSteps(): forget vectors and coefficients, keep settings */
+int eigenex_basis_clear(eigenex_basis_t b);
+
+/* host <-> device vectors (rows owned by this context) */
+int eigenex_vec_upload(eigenex_basis_t b, int vec_ref, const double* host);
+int eigenex_vec_download(eigenex_basis_t b, int vec_ref, double* host);
+
+/* ---- step primitives (each one parity-tested on its own; all synchronise) -- */
+/* y = A*x + shift*x ; if dot != NULL also *dot = x . y      (a1, a2, a3 of SURVEY 8a) */
+int eigenex_apply(eigenex_basis_t b, int x_ref, int y_ref, double shift, double* dot);
+/* h[i] = col(first + i*stride) . w, i < count, then h[count + q] = ortho(q) . w, q < n_ortho_used   (a5 dot half) */
+int eigenex_dots(eigenex_basis_t b, int w_ref, int first, int stride, int count, int n_ortho_used, double* h);
+/* w -= sum_i h[i]*col(first+i*stride) + sum_q h[count+q]*ortho(q); *nrm2 = ||w||^2   (a5 axpy half, a6) */
+int eigenex_update(eigenex_basis_t b, int w_ref, int first, int stride, int count, int n_ortho_used, const double* h,
+                   double* nrm2);
+/* z = x - a*p - b*q          (a4; q_ref may equal p_ref with b = 0) */
+int eigenex_axpy2(eigenex_basis_t b, int z_ref, int x_ref, double a, int p_ref, double bcoef, int q_ref);
+/* dst = s * src              (a7) */
+int eigenex_scale(eigenex_basis_t b, int dst_ref, int src_ref, double s);
+
+/* ---- fused steps (what the solver classes call) -------------------------- */
+/* Lanczos: start vector (setInitialVector) -> eigenex_vec_upload(b, EIGENEX_VEC_W, init).
+ * Each *_enqueue(b, ncalls) enqueues `ncalls` calls of updateLanczosSteps()/updateArnoldiSteps()
+ * WITHOUT host synchronisation; breakdown (beta <= threshold, zero start vector, residue <=
+ * threshold) is detected on the device and turns the remaining calls into no-ops, exactly as
+ * the reference would have stopped. */
+int eigenex_lanczos_enqueue(eigenex_basis_t b, int ncalls);
+int eigenex_arnoldi_enqueue(eigenex_basis_t b, int ncalls);
+
+typedef struct {
+  int32_t nvec;        /* lanczosvectors_.size() / arnoldivectors_.size() */
+  int32_t iterations;  /* iterations_ */
+  int32_t nalpha;      /* alpha_.size()  (Arnoldi: h_.size()) */
+  int32_t nbeta;       /* beta_.size() */
+  int32_t stopped;     /* 1 = a step returned false on the device (breakdown / start vector failed) */
+  int32_t calls_true;  /* number of enqueued calls that returned true since the last clear */
+  double residue;      /* Arnoldi residue_ */
+} eigenex_state_t;
+
+/* synchronises and returns the coefficients: Lanczos alpha[nalpha], beta[nbeta];
+ * Arnoldi: hess column-major with leading dimension ldh (>= nalpha+1): hess[r + c*ldh] = h_[c][r].
+ * Any output pointer may be NULL. */
+int eigenex_lanczos_state(eigenex_basis_t b, eigenex_state_t* st, double* alpha, double* beta);
+int eigenex_arnoldi_state(eigenex_basis_t b, eigenex_state_t* st, double* hess, int ldh);
+
+/* X[:, e] = sum_m S[m + e*lds] * col(m), m < nvec, e < nev; then each column is
+ * normalised and divided by the sign of its first non-zero entry
+ * (lanczos.hpp:798-816).  X is returned to the host (rows owned by this context),
+ * leading dimension ldx. */
+int eigenex_ritz_vectors(eigenex_basis_t b, int nvec, int nev, const double* S, int lds, double* X, int64_t ldx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EIGENEX_HIP_H */

@@ -1,0 +1,332 @@
+"""GPU parity tests, kernel level: every C-ABI step primitive and the fused
+Lanczos/Arnoldi steps against the CPU oracle (oracle/), through the C ABI
+(include/eigenex_hip.h) on the same seeded inputs.
+
+Tolerances (fp64): SpMV bit-exact (same multiply-then-add order as the oracle);
+dots/norms 1e-13 relative to |x||y| (summation order differs); alpha/beta 1e-12
+absolute; Ritz values 1e-10 relative (north star).
+"""
+import numpy as np
+import pytest
+
+from oracle import cref
+from oracle import krylov_oracle as ko
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from cmpt_eigenex_amd import capi as m
+
+    assert m.device_count() >= 1, "no GPU visible: the HIP path must fail loudly, not fall back"
+    return m
+
+
+def _random_csr(rng, n, max_per_row, long_row=None, empty_rows=()):
+    counts = rng.integers(0, max_per_row + 1, n)
+    for r in empty_rows:
+        counts[r] = 0
+    if long_row is not None:
+        counts[long_row[0]] = long_row[1]
+    rowptr = np.zeros(n + 1, np.int64)
+    np.cumsum(counts, out=rowptr[1:])
+    col = np.empty(rowptr[-1], np.int32)
+    for r in range(n):
+        c = counts[r]
+        col[rowptr[r]:rowptr[r + 1]] = np.sort(rng.choice(n, c, replace=False)) if c <= n else 0
+    val = rng.uniform(-1, 1, rowptr[-1])
+    return rowptr.astype(np.int32), col, val
+
+
+@pytest.mark.parametrize("shards", [1, 2, 3])
+def test_spmv_bit_exact_laplacian(capi, shards):
+    n = 20
+    N = n ** 3
+    rowptr, col, val = cref.laplacian3d(n)
+    x = np.random.default_rng(0).standard_normal(N)
+    y_ref = cref.csr_spmv(rowptr, col, val, x)
+    ctx = capi.Context(loopback_shards=shards) if shards > 1 else capi.Context()
+    for A in (capi.Csr.upload(ctx, N, rowptr, col, val), capi.Csr.laplacian3d(ctx, n)):
+        assert A.info()["nnz_local"] == rowptr[-1]
+        b = capi.Basis(ctx, A, N, 4)
+        b.upload(capi.VEC_W, x)
+        dot = b.apply(capi.VEC_W, capi.VEC_V, 0.0, want_dot=True)
+        y = b.download(capi.VEC_V)
+        np.testing.assert_array_equal(y, y_ref)
+        assert abs(dot - x @ y_ref) <= 1e-13 * np.linalg.norm(x) * np.linalg.norm(y_ref)
+        # shift and a basis column as input
+        b.upload(capi.VEC_COL(2), x)
+        b.apply(capi.VEC_COL(2), capi.VEC_COL(3), 0.5)
+        np.testing.assert_array_equal(b.download(capi.VEC_COL(3)), y_ref + 0.5 * x)
+        b.close()
+        A.close()
+    ctx.close()
+
+
+@pytest.mark.parametrize("shards", [1, 4])
+def test_spmv_irregular_rows(capi, shards):
+    """empty rows, a row longer than one LDS chunk (2048 products), ragged tail tile."""
+    rng = np.random.default_rng(1)
+    n = 5003
+    rowptr, col, val = _random_csr(rng, n, 40, long_row=(1234, 4500), empty_rows=(0, 17, 5002))
+    x = rng.standard_normal(n)
+    y_ref = cref.csr_spmv(rowptr, col, val, x)
+    ctx = capi.Context(loopback_shards=shards) if shards > 1 else capi.Context()
+    A = capi.Csr.upload(ctx, n, rowptr, col, val)
+    b = capi.Basis(ctx, A, n, 2)
+    b.upload(capi.VEC_W, x)
+    b.apply(capi.VEC_W, capi.VEC_V)
+    np.testing.assert_array_equal(b.download(capi.VEC_V), y_ref)
+    ctx.close()
+
+
+@pytest.mark.parametrize("shards", [1, 3])
+@pytest.mark.parametrize("n", [1, 63, 2048, 2049, 70001])
+def test_dots_update_axpy_scale(capi, shards, n):
+    if shards > n:
+        pytest.skip("more shards than rows")
+    rng = np.random.default_rng(n)
+    cap, nq = 11, 2
+    ctx = capi.Context(loopback_shards=shards) if shards > 1 else capi.Context()
+    A = capi.Csr.upload(ctx, n, np.arange(n + 1, dtype=np.int32), np.arange(n, dtype=np.int32), np.ones(n))
+    b = capi.Basis(ctx, A, n, cap, nq)
+    V = rng.standard_normal((cap, n))
+    Q = rng.standard_normal((nq, n))
+    w = rng.standard_normal(n)
+    for c in range(cap):
+        b.upload(capi.VEC_COL(c), V[c])
+    for q in range(nq):
+        b.upload(capi.VEC_ORTHO(q), Q[q])
+    b.upload(capi.VEC_W, w)
+    for first, stride, count, nqu in ((0, 1, cap, 0), (1, 3, 3, 2), (0, 1, 0, 2), (4, 1, 1, 0), (0, 1, 9, 1)):
+        cols = [first + i * stride for i in range(count)]
+        h = b.dots(capi.VEC_W, first, stride, count, nqu)
+        M = np.concatenate([V[cols], Q[:nqu]]) if count + nqu else np.zeros((0, n))
+        h_ref = M @ w
+        scale = np.linalg.norm(M, axis=1) * np.linalg.norm(w)
+        assert np.all(np.abs(h - h_ref) <= 1e-13 * scale + 1e-300)
+        # update on a scratch copy in V-slot... use VEC_V as the target
+        b.upload(capi.VEC_V, w)
+        nrm2 = b.update(capi.VEC_V, first, stride, count, h_ref, nqu)
+        w_new = w.copy()
+        for i in range(M.shape[0]):
+            w_new = w_new - h_ref[i] * M[i]
+        got = b.download(capi.VEC_V)
+        np.testing.assert_allclose(got, w_new, rtol=0, atol=1e-13 * (1 + np.abs(h_ref).sum()) * max(1.0, np.abs(M).max(initial=0)))
+        assert abs(nrm2 - got @ got) <= 1e-13 * (got @ got) + 1e-300
+    # axpy2 / scale
+    b.axpy2(capi.VEC_V, capi.VEC_W, 0.75, capi.VEC_COL(1), -1.25, capi.VEC_COL(0))
+    np.testing.assert_allclose(b.download(capi.VEC_V), w - 0.75 * V[1] + 1.25 * V[0], rtol=0, atol=1e-14 * 8)
+    b.scale(capi.VEC_COL(5), capi.VEC_W, 0.3)
+    np.testing.assert_array_equal(b.download(capi.VEC_COL(5)), w * 0.3)
+    ctx.close()
+
+
+def _lanczos_ref(rowptr, col, val, init, ncalls, **kw):
+    c = cref.CLanczos(rowptr, col, val, init, cap=ncalls + 1, **kw)
+    ok = c.run(ncalls)
+    return c, ok
+
+
+@pytest.mark.parametrize("shards", [1, 2, 5])
+@pytest.mark.parametrize("mode", ["batched", "sequential"])
+def test_lanczos_steps_match_oracle(capi, shards, mode):
+    n = 16
+    N = n ** 3
+    rowptr, col, val = cref.laplacian3d(n)
+    rng = np.random.default_rng(11)
+    init = rng.standard_normal(N)
+    m = 40
+    ref, ok = _lanczos_ref(rowptr, col, val, init, m + 1)
+    assert ok == m + 1
+    ctx = capi.Context(loopback_shards=shards) if shards > 1 else capi.Context()
+    A = capi.Csr.laplacian3d(ctx, n)
+    b = capi.Basis(ctx, A, N, m + 1)
+    b.configure(0.0, 1e-12, 1, capi.ORTHO_BATCHED if mode == "batched" else capi.ORTHO_SEQUENTIAL)
+    b.upload(capi.VEC_W, init)
+    b.lanczos_enqueue(m + 1)
+    st, alpha, beta = b.lanczos_state()
+    assert (st.nvec, st.iterations, st.nalpha, st.nbeta, st.stopped, st.calls_true) == (m + 1, m, m + 1, m, 0, m + 1)
+    np.testing.assert_allclose(alpha, ref.alpha, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(beta, ref.beta, rtol=0, atol=1e-12)
+    th = ko.tridiagonal_eigh(alpha, beta, vectors=False)[0]
+    th_ref = ko.tridiagonal_eigh(ref.alpha, ref.beta, vectors=False)[0]
+    np.testing.assert_allclose(th, th_ref, rtol=1e-10, atol=0)
+    # basis: orthonormal, and equal to the oracle's up to rounding
+    V = np.stack([b.download(capi.VEC_COL(c)) for c in range(m + 1)])
+    assert np.abs(V @ V.T - np.eye(m + 1)).max() < 1e-13
+    assert np.abs(V - ref.V[: m + 1]).max() < 1e-9
+    ctx.close()
+
+
+def test_lanczos_settings_shift_interval_ortho(capi):
+    n = 10
+    N = n ** 3
+    rowptr, col, val = cref.laplacian3d(n)
+    rng = np.random.default_rng(5)
+    init = rng.standard_normal(N)
+    Q = np.linalg.qr(rng.standard_normal((N, 3)))[0].T.copy()
+    ctx = capi.Context()
+    A = capi.Csr.upload(ctx, N, rowptr, col, val)
+    m = 24
+    for interval, nq, shift, mode in ((1, 3, 0.0, 0), (1, 3, 0.0, 1), (3, 2, -0.7, 0), (3, 2, -0.7, 1), (0, 0, 1.5, 0)):
+        ref, ok = _lanczos_ref(rowptr, col, val, init, m + 1, shift=shift, interval=interval, Q=list(Q[:nq]))
+        b = capi.Basis(ctx, A, N, m + 1, nq)
+        b.configure(shift, 1e-12, interval, mode)
+        for q in range(nq):
+            b.upload(capi.VEC_ORTHO(q), Q[q])
+        b.upload(capi.VEC_W, init)
+        b.lanczos_enqueue(m + 1)
+        st, alpha, beta = b.lanczos_state()
+        assert st.nvec == m + 1 and st.stopped == 0
+        tol = 1e-12 if interval == 1 else 1e-9  # partial/no reorthogonalisation amplifies rounding differences
+        np.testing.assert_allclose(alpha, ref.alpha, rtol=0, atol=tol)
+        np.testing.assert_allclose(beta, ref.beta, rtol=0, atol=tol)
+        b.close()
+    ctx.close()
+
+
+def test_lanczos_breakdown_and_zero_start(capi):
+    # diag(1,2,3,4) with a start vector in a 2-d invariant subspace (lanczos.hpp:433-437)
+    rowptr = np.arange(5, dtype=np.int32)
+    col = np.arange(4, dtype=np.int32)
+    val = np.array([1.0, 2.0, 3.0, 4.0])
+    ctx = capi.Context()
+    A = capi.Csr.upload(ctx, 4, rowptr, col, val)
+    b = capi.Basis(ctx, A, 4, 6)
+    b.upload(capi.VEC_W, np.array([1.0, 1.0, 0.0, 0.0]))
+    b.lanczos_enqueue(5)
+    st, alpha, beta = b.lanczos_state()
+    assert (st.nvec, st.nalpha, st.nbeta, st.stopped, st.calls_true, st.iterations) == (2, 2, 2, 1, 2, 1)
+    assert beta[-1] <= 1e-12
+    np.testing.assert_allclose(ko.tridiagonal_eigh(alpha, beta, vectors=False)[0], [1.0, 2.0], atol=1e-14)
+    # zero start vector: first call fails (lanczos.hpp:316-318)
+    b.clear()
+    b.upload(capi.VEC_W, np.zeros(4))
+    b.lanczos_enqueue(3)
+    st, alpha, beta = b.lanczos_state()
+    assert (st.nvec, st.nalpha, st.nbeta, st.stopped, st.calls_true) == (0, 0, 0, 1, 0)
+    # clear + good vector works again
+    b.clear()
+    b.upload(capi.VEC_W, np.array([1.0, 2.0, 3.0, 4.0]))
+    b.lanczos_enqueue(4)
+    st, alpha, beta = b.lanczos_state()
+    assert st.nvec == 4 and st.stopped == 0
+    np.testing.assert_allclose(ko.tridiagonal_eigh(alpha, beta, vectors=False)[0], [1, 2, 3, 4], atol=1e-12)
+    ctx.close()
+
+
+@pytest.mark.parametrize("shards", [1, 3])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_arnoldi_steps_match_oracle(capi, shards, mode):
+    rng = np.random.default_rng(21)
+    N, per = 3000, 8
+    col = np.stack([np.sort(rng.choice(N, per, replace=False)) for _ in range(N)]).astype(np.int32).ravel()
+    rowptr = (np.arange(N + 1) * per).astype(np.int32)
+    val = rng.uniform(-1, 1, N * per)
+    init = rng.standard_normal(N)
+    Q = np.linalg.qr(rng.standard_normal((N, 2)))[0].T.copy()
+    m = 30
+    for nq, shift in ((0, 0.0), (2, 0.3)):
+        ref = cref.CArnoldi(rowptr, col, val, init, cap=m + 1, shift=shift, Q=list(Q[:nq]))
+        assert ref.run(m) == m
+        ctx = capi.Context(loopback_shards=shards) if shards > 1 else capi.Context()
+        A = capi.Csr.upload(ctx, N, rowptr, col, val)
+        b = capi.Basis(ctx, A, N, m, nq)
+        b.configure(shift, 1e-12, 1, mode)
+        for q in range(nq):
+            b.upload(capi.VEC_ORTHO(q), Q[q])
+        b.upload(capi.VEC_W, init)
+        b.arnoldi_enqueue(m)
+        st, H = b.arnoldi_state()
+        assert (st.nvec, st.iterations, st.nalpha, st.stopped, st.calls_true) == (m, m, m, 0, m)
+        H_ref = ref.hessenberg()
+        np.testing.assert_allclose(H, H_ref, rtol=0, atol=1e-11)
+        assert abs(st.residue - ref.residue) < 1e-11
+        ev = np.sort_complex(np.linalg.eigvals(H))
+        ev_ref = np.sort_complex(np.linalg.eigvals(H_ref))
+        np.testing.assert_allclose(ev, ev_ref, rtol=1e-10, atol=1e-10)
+        V = np.stack([b.download(capi.VEC_COL(c)) for c in range(m)])
+        assert np.abs(V @ V.T - np.eye(m)).max() < 1e-12
+        ctx.close()
+
+
+def test_arnoldi_full_space_and_capacity(capi):
+    rng = np.random.default_rng(2)
+    N = 6
+    Ad = rng.standard_normal((N, N))
+    rowptr = (np.arange(N + 1) * N).astype(np.int32)
+    col = np.tile(np.arange(N, dtype=np.int32), N)
+    ctx = capi.Context()
+    A = capi.Csr.upload(ctx, N, rowptr, col, Ad.ravel())
+    b = capi.Basis(ctx, A, N, N)
+    b.upload(capi.VEC_W, rng.standard_normal(N))
+    b.arnoldi_enqueue(N)
+    b.arnoldi_enqueue(1)  # nvec == N: arnoldiStepIsUtmost -> false, nothing changes
+    st, H = b.arnoldi_state()
+    assert st.nvec == N and st.iterations == N and st.stopped == 1
+    np.testing.assert_allclose(np.sort_complex(np.linalg.eigvals(H)), np.sort_complex(np.linalg.eigvals(Ad)), atol=1e-10)
+    ctx.close()
+
+
+def test_host_operator_path(capi):
+    """operator = host callback (the reference's MatMulFunction): dense 64x64 symmetric."""
+    rng = np.random.default_rng(4)
+    N = 64
+    R = rng.standard_normal((N, N))
+    Ad = (R + R.T) / 2
+    init = rng.standard_normal(N)
+    bo = ko.LanczosBaseOracle()
+    bo.matmul = lambda x: Ad @ x
+    bo.matrix_height = N
+    bo.initial_vector = init
+    bo.eigenvalue_shift = 0.25
+    m = 20
+    for _ in range(m + 1):
+        assert bo.update_lanczos_steps()
+    ctx = capi.Context()
+    b = capi.Basis(ctx, None, N, m + 1)
+    b.configure(0.25, 1e-12, 1, 0)
+    calls = []
+
+    def op(x):
+        calls.append(1)
+        return Ad @ x
+
+    b.set_host_operator(op)
+    b.upload(capi.VEC_W, init)
+    b.lanczos_enqueue(m + 1)
+    st, alpha, beta = b.lanczos_state()
+    assert st.nvec == m + 1 and len(calls) == m + 1
+    np.testing.assert_allclose(alpha, bo.alpha, atol=1e-12)
+    np.testing.assert_allclose(beta, bo.beta, atol=1e-12)
+    ctx.close()
+
+
+@pytest.mark.parametrize("shards", [1, 3])
+def test_ritz_vectors(capi, shards):
+    n = 12
+    N = n ** 3
+    rowptr, col, val = cref.laplacian3d(n)
+    init = np.random.default_rng(9).standard_normal(N)
+    m = 60
+    ctx = capi.Context(loopback_shards=shards) if shards > 1 else capi.Context()
+    A = capi.Csr.laplacian3d(ctx, n)
+    b = capi.Basis(ctx, A, N, m + 1)
+    b.upload(capi.VEC_W, init)
+    b.lanczos_enqueue(m + 1)
+    st, alpha, beta = b.lanczos_state()
+    th, S = ko.tridiagonal_eigh(alpha, beta)
+    nev = 11  # more than one pass of 8
+    X = b.ritz_vectors(m + 1, S[:, :nev])
+    V = np.stack([b.download(capi.VEC_COL(c)) for c in range(m + 1)])
+    for e in range(nev):
+        x_ref = ko.fix_phase_and_normalize(V.T @ S[:, e])
+        np.testing.assert_allclose(X[:, e], x_ref, rtol=0, atol=1e-13)
+        assert X[np.flatnonzero(X[:, e])[0], e] > 0
+    import scipy.sparse as sp
+
+    Asp = sp.csr_matrix((val, col, rowptr), shape=(N, N))
+    assert np.linalg.norm(Asp @ X[:, 0] - th[0] * X[:, 0]) < 1e-3
+    ctx.close()
