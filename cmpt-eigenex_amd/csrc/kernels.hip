@@ -548,6 +548,21 @@ __global__ __launch_bounds__(kBlock) void k_scale_columns(double* __restrict__ X
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) x[i] *= f;
 }
 
+// complex Ritz vectors: out[(i + e*ld)*2 + {0,1}] = (X[:,2e] + i X[:,2e+1]) * (fr + i fi)
+__global__ __launch_bounds__(kBlock) void k_complex_finish(const double* __restrict__ X, int64_t ldx, int64_t n,
+                                                           const double* __restrict__ factors,
+                                                           double* __restrict__ out, int64_t ldo) {
+  const int e = blockIdx.y;
+  const double fr = factors[2 * e], fi = factors[2 * e + 1];
+  const double* xr = X + (int64_t)(2 * e) * ldx;
+  const double* xi = xr + ldx;
+  double2* o = reinterpret_cast<double2*>(out) + (int64_t)e * ldo;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const double a = xr[i], b = xi[i];
+    o[i] = make_double2(a * fr - b * fi, a * fi + b * fr);
+  }
+}
+
 int g_num_cu = 256;
 
 }  // namespace
@@ -649,6 +664,12 @@ void launch_ritz(hipStream_t s, const double* V, int64_t ldv, int nvec, const do
 
 void launch_first_nonzero(hipStream_t s, const double* X, int64_t ldx, int nev, int64_t n, double* out_idx_val) {
   hipLaunchKernelGGL(k_first_nonzero, dim3(nev), dim3(kBlock), 0, s, X, ldx, n, out_idx_val);
+}
+
+void launch_complex_finish(hipStream_t s, const double* X, int64_t ldx, int ncomplex, int64_t n,
+                           const double* factors_dev, double* out, int64_t ldo) {
+  const int gx = grid_for_tiles((n + kBlock - 1) / kBlock, 4);
+  hipLaunchKernelGGL(k_complex_finish, dim3(gx, ncomplex), dim3(kBlock), 0, s, X, ldx, n, factors_dev, out, ldo);
 }
 
 void launch_scale_columns(hipStream_t s, double* X, int64_t ldx, int nev, int64_t n, const double* factors_dev) {

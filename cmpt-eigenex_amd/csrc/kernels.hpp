@@ -98,5 +98,8 @@ void launch_ritz(hipStream_t s, const double* V, int64_t ldv, int nvec, const do
 // per column: first local index with a non-zero entry (n if none) and its value
 void launch_first_nonzero(hipStream_t s, const double* X, int64_t ldx, int nev, int64_t n, double* out_idx_val);
 void launch_scale_columns(hipStream_t s, double* X, int64_t ldx, int nev, int64_t n, const double* factors_dev);
+// out (interleaved re,im; column e at out + 2*e*ldo) = (X[:,2e] + i X[:,2e+1]) * (factors[2e] + i factors[2e+1])
+void launch_complex_finish(hipStream_t s, const double* X, int64_t ldx, int ncomplex, int64_t n,
+                           const double* factors_dev, double* out, int64_t ldo);
 
 }  // namespace eigenex

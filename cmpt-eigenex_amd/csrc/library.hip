@@ -1048,6 +1048,49 @@ int eigenex_basis_create(eigenex_context_t c, eigenex_csr_t csr, int64_t n_globa
   return 0;
 }
 
+int eigenex_basis_capacity(eigenex_basis_t b, int* capacity) {
+  if (!b || !capacity) return fail(EIGENEX_ERR_ARG, "NULL argument");
+  *capacity = b->cap;
+  return 0;
+}
+
+int eigenex_basis_reserve(eigenex_basis_t b, int capacity) {
+  if (!b) return fail(EIGENEX_ERR_ARG, "basis is NULL");
+  if (capacity <= b->cap) return 0;
+  eigenex_context_s* c = b->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  const int oldcap = b->cap, oldldh = b->ldh;
+  const int newmax = capacity + b->nq, newldh = capacity + 2;
+  for (auto& s : b->sh) {
+    const size_t vbytes = sizeof(double) * (size_t)s.ldv;
+    double *V = nullptr, *partials = nullptr, *hbuf = nullptr, *alpha = nullptr, *beta = nullptr, *H = nullptr;
+    HIPCHK(hipMalloc(&V, vbytes * capacity));
+    HIPCHK(hipMemcpyAsync(V, s.V, vbytes * oldcap, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(V + (size_t)s.ldv * oldcap, 0, vbytes * (capacity - oldcap), c->stream));
+    const int rows = std::max(newmax, 8) + 4;
+    HIPCHK(hipMalloc(&partials, sizeof(double) * (size_t)s.pstride * rows));
+    HIPCHK(hipMalloc(&hbuf, sizeof(double) * (newmax + 40)));
+    HIPCHK(hipMemsetAsync(hbuf, 0, sizeof(double) * (newmax + 40), c->stream));
+    HIPCHK(hipMalloc(&alpha, sizeof(double) * (capacity + 2)));
+    HIPCHK(hipMalloc(&beta, sizeof(double) * (capacity + 2)));
+    HIPCHK(hipMemsetAsync(alpha, 0, sizeof(double) * (capacity + 2), c->stream));
+    HIPCHK(hipMemsetAsync(beta, 0, sizeof(double) * (capacity + 2), c->stream));
+    HIPCHK(hipMemcpyAsync(alpha, s.alpha, sizeof(double) * (oldcap + 2), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(beta, s.beta, sizeof(double) * (oldcap + 2), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMalloc(&H, sizeof(double) * (size_t)newldh * (capacity + 1)));
+    HIPCHK(hipMemsetAsync(H, 0, sizeof(double) * (size_t)newldh * (capacity + 1), c->stream));
+    HIPCHK(hipMemcpy2DAsync(H, sizeof(double) * newldh, s.H, sizeof(double) * oldldh, sizeof(double) * oldldh, oldcap + 1,
+                            hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (void* p : {(void*)s.V, (void*)s.partials, (void*)s.hbuf, (void*)s.alpha, (void*)s.beta, (void*)s.H}) (void)hipFree(p);
+    s.V = V, s.partials = partials, s.hbuf = hbuf, s.alpha = alpha, s.beta = beta, s.H = H;
+  }
+  b->cap = capacity;
+  b->maxcols = newmax;
+  b->ldh = newldh;
+  return 0;
+}
+
 int eigenex_basis_set_host_operator(eigenex_basis_t b, eigenex_matvec_fn fn, void* user) {
   if (!b) return fail(EIGENEX_ERR_ARG, "basis is NULL");
   if (b->csr) return fail(EIGENEX_ERR_STATE, "this basis was created for a device CSR operator");
@@ -1240,7 +1283,65 @@ int eigenex_arnoldi_state(eigenex_basis_t b, eigenex_state_t* st, double* hess, 
   return 0;
 }
 
-// Ritz vectors (lanczos.hpp:798-816; arnoldi.hpp:841-865 for real S)
+}  // extern "C" (steps)
+
+// ---- Ritz vectors -----------------------------------------------------------------------
+namespace {
+
+// One pass over the basis for up to 8 real coefficient columns: s.X[:, e] = V * cols[e] on
+// every shard; returns the all-reduced squared norms and, per column, the value of the first
+// non-zero entry in global row order together with its global row (n_global if none).
+int ritz_chunk(eigenex_basis_s* b, int nvec, int ne, const double* const* cols, double* d_S, double* nrm2,
+               double* first_row, double* first_val) {
+  eigenex_context_s* c = b->ctx;
+  const int E = 8;
+  for (int e = 0; e < ne; ++e)
+    HIPCHK(hipMemcpyAsync(d_S + (size_t)e * nvec, cols[e], sizeof(double) * nvec, hipMemcpyHostToDevice, c->stream));
+  for (auto& s : b->sh) {
+    {
+      ProfScope ps(c, EIGENEX_K_RITZ, 8.0 * s.nloc * nvec + 8.0 * s.nloc * ne);
+      launch_ritz(c->stream, s.V, s.ldv, nvec, d_S, nvec, ne, s.X, s.ldv, s.nloc, s.partials, s.pstride, s.g_vec);
+    }
+    launch_reduce(c->stream, s.partials, s.pstride, s.g_vec, ne, s.hbuf, s.ctrl_zero);
+  }
+  CHK(allreduce(b, 0, ne));  // hbuf[0..ne) = ||x_e||^2
+  for (auto& s : b->sh) launch_first_nonzero(c->stream, s.X, s.ldv, ne, s.nloc, s.hbuf + E);
+  std::vector<double> idxval((size_t)2 * E * c->P, 0.0);
+  if (c->loopback || c->P == 1) {
+    for (size_t i = 0; i < b->sh.size(); ++i)
+      HIPCHK(hipMemcpyAsync(idxval.data() + 2 * E * i, b->sh[i].hbuf + E, sizeof(double) * 2 * ne, hipMemcpyDeviceToHost, c->stream));
+  } else {
+    double* tmp = nullptr;
+    HIPCHK(hipMalloc(&tmp, sizeof(double) * 2 * E * c->P));
+    NCCLCHK(ncclAllGather(b->sh[0].hbuf + E, tmp, (size_t)2 * E, ncclDouble, c->comm, c->stream));
+    HIPCHK(hipMemcpyAsync(idxval.data(), tmp, sizeof(double) * 2 * E * c->P, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)hipFree(tmp);
+  }
+  HIPCHK(hipMemcpyAsync(nrm2, b->sh[0].hbuf, sizeof(double) * ne, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (int e = 0; e < ne; ++e) {
+    first_row[e] = (double)b->n_global;
+    first_val[e] = 0.0;
+    for (int p = 0; p < c->P; ++p) {  // shards in row order: the first one with a hit wins
+      int64_t pb, pe;
+      partition(b->n_global, c->P, p, &pb, &pe);
+      const double idx = idxval[(size_t)2 * E * p + 2 * e];
+      if (idx < (double)(pe - pb)) {
+        first_row[e] = (double)pb + idx;
+        first_val[e] = idxval[(size_t)2 * E * p + 2 * e + 1];
+        break;
+      }
+    }
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// real coefficients (lanczos.hpp:798-816)
 int eigenex_ritz_vectors(eigenex_basis_t b, int nvec, int nev, const double* S, int lds, double* X, int64_t ldx) {
   if (!b || nvec < 0 || nvec > b->cap || nev < 0 || (nev && (!S || !X)) || lds < nvec) return fail(EIGENEX_ERR_ARG, "eigenex_ritz_vectors: bad argument");
   eigenex_context_s* c = b->ctx;
@@ -1251,57 +1352,22 @@ int eigenex_ritz_vectors(eigenex_basis_t b, int nvec, int nev, const double* S, 
   const int E = 8;
   double* d_S = nullptr;
   HIPCHK(hipMalloc(&d_S, sizeof(double) * (size_t)std::max(nvec, 1) * E));
-  std::vector<double> hostbuf((size_t)4 * E * b->sh.size());
   int rc = [&]() -> int {
     for (auto& s : b->sh)
       if (!s.X) HIPCHK(hipMalloc(&s.X, sizeof(double) * (size_t)s.ldv * E));
     for (int e0 = 0; e0 < nev; e0 += E) {
       const int ne = std::min(E, nev - e0);
-      for (int e = 0; e < ne; ++e)
-        HIPCHK(hipMemcpyAsync(d_S + (size_t)e * nvec, S + (size_t)(e0 + e) * lds, sizeof(double) * nvec, hipMemcpyHostToDevice, c->stream));
-      for (auto& s : b->sh) {
-        {
-          ProfScope ps(c, EIGENEX_K_RITZ, 8.0 * s.nloc * nvec + 8.0 * s.nloc * ne);
-          launch_ritz(c->stream, s.V, s.ldv, nvec, d_S, nvec, ne, s.X, s.ldv, s.nloc, s.partials, s.pstride, s.g_vec);
-        }
-        launch_reduce(c->stream, s.partials, s.pstride, s.g_vec, ne, s.hbuf, s.ctrl_zero);
-      }
-      CHK(allreduce(b, 0, ne));  // hbuf[0..ne) = ||x_e||^2
-      // first non-zero entry over the whole (sharded) column
-      for (auto& s : b->sh) launch_first_nonzero(c->stream, s.X, s.ldv, ne, s.nloc, s.hbuf + E);
-      std::vector<double> idxval((size_t)2 * E * c->P, 0.0);
-      if (c->loopback || c->P == 1) {
-        for (size_t i = 0; i < b->sh.size(); ++i)
-          HIPCHK(hipMemcpyAsync(idxval.data() + 2 * E * i, b->sh[i].hbuf + E, sizeof(double) * 2 * ne, hipMemcpyDeviceToHost, c->stream));
-      } else {
-        double* tmp = nullptr;
-        HIPCHK(hipMalloc(&tmp, sizeof(double) * 2 * E * c->P));
-        NCCLCHK(ncclAllGather(b->sh[0].hbuf + E, tmp, (size_t)2 * E, ncclDouble, c->comm, c->stream));
-        HIPCHK(hipMemcpyAsync(idxval.data(), tmp, sizeof(double) * 2 * E * c->P, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        (void)hipFree(tmp);
-      }
-      std::vector<double> nrm2(E, 0.0);
-      HIPCHK(hipMemcpyAsync(nrm2.data(), b->sh[0].hbuf, sizeof(double) * ne, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(hipStreamSynchronize(c->stream));
-      std::vector<double> factors(E, 1.0);
+      const double* cols[E];
+      for (int e = 0; e < ne; ++e) cols[e] = S + (size_t)(e0 + e) * lds;
+      double nrm2[E], frow[E], fval[E], factors[E];
+      CHK(ritz_chunk(b, nvec, ne, cols, d_S, nrm2, frow, fval));
       for (int e = 0; e < ne; ++e) {
-        double phase = 1.0;
-        for (int p = 0; p < c->P; ++p) {  // shards in row order: the first one with a hit wins
-          int64_t pb, pe;
-          partition(b->n_global, c->P, p, &pb, &pe);
-          const double idx = idxval[(size_t)2 * E * p + 2 * e];
-          if (idx < (double)(pe - pb)) {
-            const double v = idxval[(size_t)2 * E * p + 2 * e + 1];
-            phase = v / std::fabs(v);  // lanczos.hpp:809-813
-            break;
-          }
-        }
+        const double phase = fval[e] != 0.0 ? fval[e] / std::fabs(fval[e]) : 1.0;  // lanczos.hpp:807-815
         const double nrm = std::sqrt(nrm2[e]);
         factors[e] = (nrm > 0.0 ? 1.0 / nrm : 1.0) * (1.0 / phase);  // :816
       }
       for (auto& s : b->sh) {
-        HIPCHK(hipMemcpyAsync(s.hbuf, factors.data(), sizeof(double) * ne, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(s.hbuf, factors, sizeof(double) * ne, hipMemcpyHostToDevice, c->stream));
         launch_scale_columns(c->stream, s.X, s.ldv, ne, s.nloc, s.hbuf);
         for (int e = 0; e < ne; ++e)
           HIPCHK(hipMemcpyAsync(X + (size_t)(e0 + e) * ldx + (s.rb - b->sh[0].rb), s.X + (size_t)e * s.ldv, sizeof(double) * s.nloc, hipMemcpyDeviceToHost, c->stream));
@@ -1310,6 +1376,69 @@ int eigenex_ritz_vectors(eigenex_basis_t b, int nvec, int nev, const double* S, 
     }
     return 0;
   }();
+  (void)hipFree(d_S);
+  return rc;
+}
+
+// complex coefficients (arnoldi.hpp:841-865): 4 complex columns per pass over the basis
+int eigenex_ritz_vectors_complex(eigenex_basis_t b, int nvec, int nev, const double* S_re, const double* S_im, int lds,
+                                 double* X, int64_t ldx) {
+  if (!b || nvec < 0 || nvec > b->cap || nev < 0 || (nev && (!S_re || !S_im || !X)) || lds < nvec) return fail(EIGENEX_ERR_ARG, "eigenex_ritz_vectors_complex: bad argument");
+  eigenex_context_s* c = b->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  int64_t nrows = 0;
+  for (auto& s : b->sh) nrows += s.nloc;
+  if (nev && ldx < nrows) return fail(EIGENEX_ERR_ARG, "ldx too small");
+  const int E = 8, EC = 4;
+  double* d_S = nullptr;
+  HIPCHK(hipMalloc(&d_S, sizeof(double) * (size_t)std::max(nvec, 1) * E));
+  std::vector<double*> outbuf(b->sh.size(), nullptr);
+  int rc = [&]() -> int {
+    for (size_t i = 0; i < b->sh.size(); ++i) {
+      BasisShard& s = b->sh[i];
+      if (!s.X) HIPCHK(hipMalloc(&s.X, sizeof(double) * (size_t)s.ldv * E));
+      HIPCHK(hipMalloc(&outbuf[i], sizeof(double) * (size_t)s.ldv * E));
+    }
+    for (int e0 = 0; e0 < nev; e0 += EC) {
+      const int nc = std::min(EC, nev - e0);
+      const double* cols[E];
+      for (int e = 0; e < nc; ++e) {
+        cols[2 * e] = S_re + (size_t)(e0 + e) * lds;
+        cols[2 * e + 1] = S_im + (size_t)(e0 + e) * lds;
+      }
+      double nrm2[E], frow[E], fval[E], factors[E];
+      CHK(ritz_chunk(b, nvec, 2 * nc, cols, d_S, nrm2, frow, fval));
+      for (int e = 0; e < nc; ++e) {
+        // first entry with |z| > 0: the earlier of the first non-zero real / imaginary parts
+        const double r0 = std::min(frow[2 * e], frow[2 * e + 1]);
+        double pr = 1.0, pi = 0.0;
+        if (r0 < (double)b->n_global) {
+          const double zr = frow[2 * e] == r0 ? fval[2 * e] : 0.0;
+          const double zi = frow[2 * e + 1] == r0 ? fval[2 * e + 1] : 0.0;
+          const double az = std::hypot(zr, zi);
+          pr = zr / az;  // phase_factor = value / abs  (arnoldi.hpp:855-862)
+          pi = zi / az;
+        }
+        const double nrm = std::sqrt(nrm2[2 * e] + nrm2[2 * e + 1]);
+        const double inv = nrm > 0.0 ? 1.0 / nrm : 1.0;
+        // (1/phase) * normalized = conj(phase) * x / nrm   (|phase| = 1)
+        factors[2 * e] = pr * inv;
+        factors[2 * e + 1] = -pi * inv;
+      }
+      for (size_t i = 0; i < b->sh.size(); ++i) {
+        BasisShard& s = b->sh[i];
+        HIPCHK(hipMemcpyAsync(s.hbuf, factors, sizeof(double) * 2 * nc, hipMemcpyHostToDevice, c->stream));
+        launch_complex_finish(c->stream, s.X, s.ldv, nc, s.nloc, s.hbuf, outbuf[i], s.ldv);
+        for (int e = 0; e < nc; ++e)
+          HIPCHK(hipMemcpyAsync(X + 2 * ((size_t)(e0 + e) * ldx + (s.rb - b->sh[0].rb)), outbuf[i] + 2 * (size_t)e * s.ldv,
+                                sizeof(double) * 2 * s.nloc, hipMemcpyDeviceToHost, c->stream));
+      }
+      HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+  }();
+  for (double* p : outbuf)
+    if (p) (void)hipFree(p);
   (void)hipFree(d_S);
   return rc;
 }

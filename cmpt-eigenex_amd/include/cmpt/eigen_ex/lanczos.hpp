@@ -1,0 +1,801 @@
+// Lanczos eigensolver with the interface of versmc/cmpt-eigenex
+// (reference include/cmpt/eigen_ex/lanczos.hpp: LanczosBase :104-461,
+// LanczosEigenSolver :468-927), re-implemented for AMD MI355X: the class keeps
+// the settings, the control flow, the log and the small projected eigenproblem
+// on the host; every operation on N-vectors (operator application, dots,
+// Gram-Schmidt updates, norms, scaling, Ritz vectors) runs in hand-written HIP
+// kernels behind the C ABI of include/eigenex_hip.h.  Header-only, like the
+// reference; link with -leigenex_hip.
+//
+// Differences a reference user should know (all additive):
+//   * setDeviceOperator(CsrOperator): a device-resident CSR matrix as the operator.
+//     The std::function operator (setMatrixMultiplication) still works: it is
+//     called on the host with host pointers, exactly as in the reference, while the
+//     vector work stays on the GPU (the vector is staged through pinned memory).
+//   * info(): Eigen-style status derived from the same events the reference logs.
+//   * Scalar = double only in this release (complex kernels: see DESIGN.md, out of scope list).
+//   * VectorType/MatrixType are cmpt::EigenEx::DenseVector/DenseMatrix (dense.hpp),
+//     convertible from/to Eigen types when Eigen is present.
+//   * es_tri() (an Eigen solver object) is replaced by tridiagonalEigenvalues() /
+//     tridiagonalEigenvectors().
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <functional>
+#include <map>
+#include <memory>
+#include <random>
+#include <string>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#include "dense.hpp"
+#include "device.hpp"
+#include "small_eigen.hpp"
+
+namespace cmpt {
+namespace EigenEx {
+
+// default convergence tolerance per scalar type (reference lanczos.hpp:62-83)
+template <class Scalar>
+class DefaultTolerance {
+ public:
+  static constexpr Scalar value() { return std::is_same<Scalar, float>::value ? Scalar(1.0e-4) : Scalar(1.0e-12); }
+};
+
+// Eigen::ComputationInfo look-alike for info() (the reference has no info())
+enum ComputationInfo { Success = 0, NumericalIssue = 1, NoConvergence = 2, InvalidInput = 3 };
+
+enum class Orthogonalization {
+  Batched = EIGENEX_ORTHO_BATCHED,       // one dots pass + one update pass per step (default)
+  Sequential = EIGENEX_ORTHO_SEQUENTIAL  // the reference's strictly sequential modified Gram-Schmidt
+};
+
+namespace detail {
+
+// normalised Gaussian vector: reference random.hpp:89-101 with util.hpp:132-148
+template <class URBG>
+inline DenseVector<double> gaussianUnitVector(URBG& g, Index size) {
+  std::normal_distribution<double> dist;
+  DenseVector<double> v(size < 0 ? 0 : size);
+  for (Index i = 0; i < v.size(); ++i) v[i] = dist(g);
+  const double nrm = v.norm();
+  if (nrm > 0.0)
+    for (Index i = 0; i < v.size(); ++i) v[i] /= nrm;
+  return v;
+}
+
+struct HostOperatorThunk {
+  std::function<void(const double*, double*)> fn;
+  static void call(const double* in, double* out, void* user) { static_cast<HostOperatorThunk*>(user)->fn(in, out); }
+};
+
+// Device Krylov state shared by LanczosBase and ArnoldiBase: owns the basis
+// handle and mirrors what the device has computed.
+class KrylovDevice {
+ public:
+  ~KrylovDevice() { release(); }
+  void release() {
+    if (basis_) eigenex_basis_destroy(basis_);
+    basis_ = nullptr;
+  }
+  bool alive() const { return basis_ != nullptr; }
+  eigenex_basis_t handle() const { return basis_; }
+
+  void create(const std::shared_ptr<device::Context>& ctx, const std::shared_ptr<device::CsrOperator>& op, Index n,
+              int capacity, int n_ortho) {
+    release();
+    ctx_ = ctx;
+    device::check(eigenex_basis_create(ctx->handle(), op ? op->handle() : nullptr, n, capacity, n_ortho, &basis_), "eigenex_basis_create");
+    n_global_ = n;
+    // rows of host vectors this process sees
+    if (ctx->shardsLocal() == ctx->shardsTotal()) {
+      row_begin_ = 0;
+      n_rows_ = n;
+    } else {
+      std::int64_t b, e;
+      device::check(eigenex_partition(n, ctx->worldSize(), ctx->rank(), &b, &e), "eigenex_partition");
+      row_begin_ = b;
+      n_rows_ = e - b;
+    }
+  }
+  void reserve(int capacity) { device::check(eigenex_basis_reserve(basis_, capacity), "eigenex_basis_reserve"); }
+  int capacity() const {
+    int c = 0;
+    device::check(eigenex_basis_capacity(basis_, &c), "eigenex_basis_capacity");
+    return c;
+  }
+  Index rowBegin() const { return row_begin_; }
+  Index localRows() const { return n_rows_; }
+  // host vector of global or local length -> pointer to the local rows
+  const double* localSlice(const DenseVector<double>& v) const {
+    if (v.size() == n_rows_) return v.data();
+    if (v.size() == n_global_) return v.data() + row_begin_;
+    throw LanczosException("vector length matches neither the matrix height nor this rank's row count");
+  }
+  void upload(int ref, const DenseVector<double>& v) { device::check(eigenex_vec_upload(basis_, ref, localSlice(v)), "eigenex_vec_upload"); }
+  DenseVector<double> download(int ref) const {
+    DenseVector<double> v(n_rows_);
+    device::check(eigenex_vec_download(basis_, ref, v.data()), "eigenex_vec_download");
+    return v;
+  }
+
+ private:
+  std::shared_ptr<device::Context> ctx_;
+  eigenex_basis_t basis_ = nullptr;
+  Index n_global_ = 0, row_begin_ = 0, n_rows_ = 0;
+};
+
+}  // namespace detail
+
+// ---------------------------------------------------------------------------
+// LanczosBase: generates the Krylov basis, alpha (diagonal) and beta
+// (sub-diagonal).  Reference: lanczos.hpp:104-461.
+// ---------------------------------------------------------------------------
+template <class Scalar_>
+class LanczosBase {
+  static_assert(std::is_same<Scalar_, double>::value, "cmpt-eigenex_amd: the device path implements Scalar = double");
+
+ public:
+  using Index = EigenEx::Index;
+  using Scalar = Scalar_;
+  using RealScalar = double;
+  using VectorType = DenseVector<Scalar>;
+  using RealVectorType = DenseVector<RealScalar>;
+  using MatrixType = DenseMatrix<Scalar>;
+  using MatMulFunction = std::function<void(const Scalar*, Scalar*)>;
+
+  // random normalised vector, usable as an initial vector (reference :124-135)
+  template <class URBG>
+  static VectorType makeRandomVector(URBG& g, Index size) {
+    return detail::gaussianUnitVector(g, size);
+  }
+
+  // ---- settings (reference :161-227) ----
+  Index reserveSize() const { return reserveSize_; }
+  LanczosBase& setReserveSize(Index resSize) {
+    reserveSize_ = resSize;
+    return *this;
+  }
+
+  const std::vector<VectorType>& orthogonalizingVectors() const { return orthogonalizingVectors_; }
+  std::vector<VectorType>& refOrthogonalizingVectors() {
+    orthoDirty_ = true;
+    return orthogonalizingVectors_;
+  }
+  LanczosBase& setOrthogonalizingVectors(const std::vector<VectorType>& orthoVec) {
+    orthogonalizingVectors_ = orthoVec;
+    orthoDirty_ = true;
+    return *this;
+  }
+  LanczosBase& setOrthogonalizingVectors(std::vector<VectorType>&& orthoVec) {
+    orthogonalizingVectors_.swap(orthoVec);
+    orthoDirty_ = true;
+    return *this;
+  }
+
+  const MatMulFunction& matrixMultiplication() const { return matrixMultiplication_; }
+  LanczosBase& setMatrixMultiplication(const MatMulFunction& matmul, Index height) {
+    matrixMultiplication_ = matmul;
+    matrixHeight_ = height;
+    deviceOperator_.reset();
+    return *this;
+  }
+  LanczosBase& setMatrixMultiplication(MatMulFunction&& matmul, Index height) {
+    std::swap(matrixMultiplication_, matmul);
+    matrixHeight_ = height;
+    deviceOperator_.reset();
+    return *this;
+  }
+  Index matrixHeight() const { return matrixHeight_; }
+
+  // device-resident operator (CSR on the GPU); replaces the callback
+  LanczosBase& setDeviceOperator(const std::shared_ptr<device::CsrOperator>& op) {
+    deviceOperator_ = op;
+    matrixMultiplication_ = nullptr;
+    matrixHeight_ = op ? static_cast<Index>(op->rows()) : 0;
+    if (op) context_ = op->context();
+    return *this;
+  }
+  const std::shared_ptr<device::CsrOperator>& deviceOperator() const { return deviceOperator_; }
+  // GPU used for the vector work when the operator is a host callback (default: device 0)
+  LanczosBase& setDeviceContext(const std::shared_ptr<device::Context>& ctx) {
+    context_ = ctx;
+    return *this;
+  }
+  Orthogonalization orthogonalization() const { return ortho_; }
+  LanczosBase& setOrthogonalization(Orthogonalization o) {
+    ortho_ = o;
+    return *this;
+  }
+
+  RealScalar eigenvalueShift() const { return eigenvalueShift_; }
+  LanczosBase& setEigenvalueShift(RealScalar eishift) {
+    eigenvalueShift_ = eishift;
+    return *this;
+  }
+
+  Index reorthogonalizeInterval() const { return reorthogonalizeInterval_; }  // the reference's getter is typed bool (:194)
+  LanczosBase& setReorthogonalizeInterval(Index reorthoInterval) {
+    reorthogonalizeInterval_ = reorthoInterval;
+    return *this;
+  }
+
+  const VectorType& initialVector() const { return initialVector_; }
+  LanczosBase& setInitialVector(const VectorType& inivec) {
+    initialVector_ = inivec;
+    return *this;
+  }
+  LanczosBase& setInitialVector(VectorType&& inivec) {
+    initialVector_ = std::move(inivec);
+    return *this;
+  }
+  // random contents from a default-seeded std::mt19937 (reference :214-218)
+  LanczosBase& setInitialVector() {
+    std::mt19937 rengine;
+    setInitialVector(makeRandomVector(rengine, matrixHeight_));
+    return *this;
+  }
+
+  RealScalar threshold() const { return threshold_; }
+  LanczosBase& setThreshold(RealScalar thre) {
+    threshold_ = thre;
+    return *this;
+  }
+
+  // ---- computed data (reference :243-248) ----
+  Index iterations() const { return iterations_; }
+  // host copies of the basis vectors, downloaded from the GPU on first access
+  const std::vector<VectorType>& lanczosvectors() const {
+    if (static_cast<Index>(vectorCache_.size()) > nvec_) vectorCache_.resize(static_cast<std::size_t>(nvec_));
+    while (static_cast<Index>(vectorCache_.size()) < nvec_)
+      vectorCache_.push_back(dev_.download(EIGENEX_VEC_COL(static_cast<int>(vectorCache_.size()))));
+    return vectorCache_;
+  }
+  // number of basis vectors without downloading them
+  Index lanczosvectorsSize() const { return nvec_; }
+  const std::vector<RealScalar>& alpha() const { return alpha_; }
+  const std::vector<RealScalar>& beta() const { return beta_; }
+
+  LanczosBase() { setAllSettingsDefault(); }
+  LanczosBase(const LanczosBase&) = delete;
+  LanczosBase& operator=(const LanczosBase&) = delete;
+
+  // defaults of the reference (:260-271); does not clear computed data
+  LanczosBase& setAllSettingsDefault() {
+    setReserveSize(128);
+    setOrthogonalizingVectors(std::vector<VectorType>());
+    matrixMultiplication_ = [](const Scalar*, Scalar*) {};
+    matrixHeight_ = 0;
+    deviceOperator_.reset();
+    setEigenvalueShift(0.0);
+    setReorthogonalizeInterval(1);
+    setInitialVector();
+    setThreshold(DefaultTolerance<RealScalar>::value());
+    return *this;
+  }
+
+  // forget vectors, alpha, beta; keep the settings (reference :277-283)
+  void clearLanczosSteps() {
+    iterations_ = 0;
+    nvec_ = 0;
+    alpha_.clear();
+    beta_.clear();
+    vectorCache_.clear();
+    callsEnqueued_ = callsRevealed_ = 0;
+    devCallsTrue_ = 0;
+    devAlpha_.clear();
+    devBeta_.clear();
+    stopApplied_ = false;
+    started_ = false;
+    if (dev_.alive()) device::check(eigenex_basis_clear(dev_.handle()), "eigenex_basis_clear");
+  }
+
+  void clear() {
+    clearLanczosSteps();
+    setAllSettingsDefault();
+  }
+
+  // Validates the settings for the first vector (reference :299-323).  The
+  // deflation by orthogonalizingVectors_ and the normalisation happen on the GPU
+  // as part of the first updateLanczosSteps().
+  void setInitialLanczosvector() {
+    if (matrixHeight_ < 0) throw LanczosException("matrixHeight_ < 0");
+    if (matrixHeight_ != initialVector_.size() && !(dev_.alive() && initialVector_.size() == dev_.localRows())) setInitialVector();
+  }
+
+  // is the Krylov space exhausted? (reference :331-347)
+  bool lanczosStepIsUtmost() const {
+    if (nvec_ == matrixHeight_) return true;
+    if (!beta_.empty()) return beta_.back() <= threshold_;
+    return false;
+  }
+
+  bool hasOperator() const { return deviceOperator_ || static_cast<bool>(matrixMultiplication_); }
+
+  // One Lanczos step (reference :371-457).  First call: u0, alpha0, v = A u0.
+  // Later calls: beta_{k}, u_{k+1}, alpha_{k+1}, v = A u_{k+1}.  Returns false when no
+  // step could be made (invalid start vector, breakdown beta <= threshold).
+  bool updateLanczosSteps() {
+    if (matrixHeight_ <= 0) return false;
+    if (!hasOperator()) return false;
+    if (callsRevealed_ == callsEnqueued_) enqueue_(1);
+    return reveal_();
+  }
+
+  // Extension: run `ncalls` calls of updateLanczosSteps() on the GPU back to back with a
+  // single host synchronisation; the following `ncalls` updateLanczosSteps() calls only
+  // reveal their results.  Identical results, no per-step round trip.
+  void prefetchLanczosSteps(Index ncalls) {
+    if (matrixHeight_ <= 0 || !hasOperator()) return;
+    const Index pending = callsEnqueued_ - callsRevealed_;
+    if (ncalls > pending) enqueue_(ncalls - pending);
+  }
+
+  // Extension: exact number of basis vectors the run will need, when known (maxIterations + 1).
+  // Sizes the device slab instead of reserveSize() (which the reference stores but never uses, :151).
+  void reserveBasis(Index nvec) { capacityHint_ = nvec; }
+
+  // Ritz vectors X = V S on the GPU, normalised and phase-fixed (reference :798-816);
+  // S is column-major lanczosvectors().size() x nev
+  MatrixType ritzVectors(const RealScalar* S, Index lds, Index nev) const {
+    MatrixType X(dev_.alive() ? dev_.localRows() : matrixHeight_, nev);
+    if (nev > 0 && nvec_ > 0)
+      device::check(eigenex_ritz_vectors(dev_.handle(), static_cast<int>(nvec_), static_cast<int>(nev), S, static_cast<int>(lds),
+                                         X.data(), X.rows()),
+                    "eigenex_ritz_vectors");
+    return X;
+  }
+
+ protected:
+  std::shared_ptr<device::Context> contextOrDefault_() {
+    if (!context_) context_ = device::defaultContext();
+    return context_;
+  }
+
+  void ensureDevice_(Index vectorsNeeded) {
+    const int nq = static_cast<int>(orthogonalizingVectors_.size());
+    const Index planned = capacityHint_ > 0 ? capacityHint_ : reserveSize_;
+    const Index want = std::max<Index>(std::max<Index>(vectorsNeeded, std::min<Index>(planned, matrixHeight_ + 1)), 2);
+    if (!dev_.alive() || devHeight_ != matrixHeight_ || devNq_ != nq || devOp_ != deviceOperator_.get()) {
+      dev_.create(contextOrDefault_(), deviceOperator_, matrixHeight_, static_cast<int>(want), nq);
+      devHeight_ = matrixHeight_;
+      devNq_ = nq;
+      devOp_ = deviceOperator_.get();
+      orthoDirty_ = true;
+    } else if (dev_.capacity() < vectorsNeeded) {
+      dev_.reserve(static_cast<int>(std::max<Index>(vectorsNeeded, 2 * dev_.capacity())));
+    }
+    if (!deviceOperator_) {
+      thunk_.fn = matrixMultiplication_;
+      device::check(eigenex_basis_set_host_operator(dev_.handle(), &detail::HostOperatorThunk::call, &thunk_), "eigenex_basis_set_host_operator");
+    }
+    device::check(eigenex_basis_configure(dev_.handle(), eigenvalueShift_, threshold_, reorthogonalizeInterval_, static_cast<int>(ortho_)),
+                  "eigenex_basis_configure");
+    if (orthoDirty_) {
+      for (int q = 0; q < nq; ++q) dev_.upload(EIGENEX_VEC_ORTHO(q), orthogonalizingVectors_[static_cast<std::size_t>(q)]);
+      orthoDirty_ = false;
+    }
+  }
+
+  void enqueue_(Index ncalls) {
+    if (ncalls <= 0) return;
+    // every successful call adds one vector
+    ensureDevice_(callsEnqueued_ + ncalls);
+    if (!started_) {
+      setInitialLanczosvector();
+      dev_.upload(EIGENEX_VEC_W, initialVector_);
+      started_ = true;
+    }
+    device::check(eigenex_lanczos_enqueue(dev_.handle(), static_cast<int>(ncalls)), "eigenex_lanczos_enqueue");
+    callsEnqueued_ += ncalls;
+    eigenex_state_t st;
+    devAlpha_.resize(static_cast<std::size_t>(callsEnqueued_ + 2));
+    devBeta_.resize(static_cast<std::size_t>(callsEnqueued_ + 2));
+    device::check(eigenex_lanczos_state(dev_.handle(), &st, devAlpha_.data(), devBeta_.data()), "eigenex_lanczos_state");
+    devAlpha_.resize(static_cast<std::size_t>(st.nalpha));
+    devBeta_.resize(static_cast<std::size_t>(st.nbeta));
+    devCallsTrue_ = st.calls_true;
+  }
+
+  bool reveal_() {
+    const Index i = callsRevealed_++;
+    if (i < devCallsTrue_) {
+      nvec_ = i + 1;
+      alpha_.assign(devAlpha_.begin(), devAlpha_.begin() + (i + 1));
+      beta_.assign(devBeta_.begin(), devBeta_.begin() + i);
+      iterations_ = i;
+      return true;
+    }
+    if (!stopApplied_) {
+      stopApplied_ = true;
+      // breakdown: the small beta stays in beta_ while the vector is dropped (reference :433-437);
+      // a failed start vector leaves everything empty (:316-318)
+      if (devCallsTrue_ > 0) beta_.assign(devBeta_.begin(), devBeta_.end());
+    }
+    return false;
+  }
+
+  // settings
+  Index reserveSize_ = 128;
+  Index capacityHint_ = 0;
+  std::vector<VectorType> orthogonalizingVectors_;
+  MatMulFunction matrixMultiplication_;
+  std::shared_ptr<device::CsrOperator> deviceOperator_;
+  std::shared_ptr<device::Context> context_;
+  Orthogonalization ortho_ = Orthogonalization::Batched;
+  RealScalar eigenvalueShift_ = 0.0;
+  Index matrixHeight_ = 0;
+  Index reorthogonalizeInterval_ = 1;
+  VectorType initialVector_;
+  RealScalar threshold_ = 1e-12;
+
+  // computed data visible to the caller
+  Index iterations_ = 0;
+  Index nvec_ = 0;
+  std::vector<RealScalar> alpha_, beta_;
+  mutable std::vector<VectorType> vectorCache_;
+
+  // device side
+  mutable detail::KrylovDevice dev_;
+  detail::HostOperatorThunk thunk_;
+  Index devHeight_ = -1;
+  int devNq_ = -1;
+  const device::CsrOperator* devOp_ = nullptr;
+  bool orthoDirty_ = true;
+  bool started_ = false;
+  Index callsEnqueued_ = 0, callsRevealed_ = 0, devCallsTrue_ = 0;
+  std::vector<double> devAlpha_, devBeta_;
+  bool stopApplied_ = false;
+};
+
+// ---------------------------------------------------------------------------
+// LanczosEigenSolver (reference :468-927)
+// ---------------------------------------------------------------------------
+template <class Scalar_>
+class LanczosEigenSolver {
+ public:
+  using Index = EigenEx::Index;
+  using Scalar = Scalar_;
+  using RealScalar = double;
+  using VectorType = DenseVector<Scalar>;
+  using RealVectorType = DenseVector<RealScalar>;
+  using MatrixType = DenseMatrix<Scalar>;
+  using RealMatrixType = DenseMatrix<RealScalar>;
+  using MatMulFunction = std::function<void(const Scalar*, Scalar*)>;
+
+  // log line prefixes (reference :486-489)
+  static std::string headERROR() { return std::string("ERROR     "); }
+  static std::string headWARN() { return std::string("WARN      "); }
+  static std::string headINFO() { return std::string("INFO      "); }
+  static std::string headDEBUG() { return std::string("DEBUG     "); }
+
+  static constexpr Index unlimited = -1;  // for minIterations / maxIterations / maxEigenvalues
+
+  template <class URBG>
+  static VectorType makeRandomVector(URBG& g, Index size) {
+    return LanczosBase<Scalar>::makeRandomVector(g, size);
+  }
+
+  // ---- front-end settings (reference :517-555) ----
+  Index minIterations() const { return minIterations_; }
+  LanczosEigenSolver& setMinIterations(Index miniter) {
+    minIterations_ = miniter;
+    return *this;
+  }
+  Index maxIterations() const { return maxIterations_; }
+  LanczosEigenSolver& setMaxIterations(Index maxiter) {
+    maxIterations_ = maxiter;
+    return *this;
+  }
+  RealScalar tolerance() const { return tolerance_; }
+  LanczosEigenSolver& setTolerance(RealScalar toler) {
+    tolerance_ = toler;
+    return *this;
+  }
+  const std::vector<Index>& indicesForConvergence() const { return indicesForConvergence_; }
+  LanczosEigenSolver& setIndicesForConvergence(const std::vector<Index>& iCovs) {
+    indicesForConvergence_ = iCovs;
+    return *this;
+  }
+  Index maxEigenvalues() const { return maxEigenvalues_; }
+  LanczosEigenSolver& setMaxEigenvalues(Index maxeivals) {
+    maxEigenvalues_ = maxeivals;
+    return *this;
+  }
+  Index computeEigenvectorsOn() const { return computeEigenvectorsOn_; }
+  LanczosEigenSolver& setComputeEigenvectorsOn(bool cEivecOn) {
+    computeEigenvectorsOn_ = cEivecOn;
+    return *this;
+  }
+
+  // ---- pass-through to the base (reference :564-628) ----
+  const LanczosBase<Scalar>& lanczosBase() const { return lanczosBase_; }
+  Index reserveSize() const { return lanczosBase_.reserveSize(); }
+  LanczosEigenSolver& setReserveSize(Index resSize) {
+    lanczosBase_.setReserveSize(resSize);
+    return *this;
+  }
+  const std::vector<VectorType>& orthogonalizingVectors() const { return lanczosBase_.orthogonalizingVectors(); }
+  std::vector<VectorType>& refOrthogonalizingVectors() { return lanczosBase_.refOrthogonalizingVectors(); }
+  LanczosEigenSolver& setOrthogonalizingVectors(const std::vector<VectorType>& orthoVec) {
+    lanczosBase_.setOrthogonalizingVectors(orthoVec);
+    return *this;
+  }
+  LanczosEigenSolver& setOrthogonalizingVectors(std::vector<VectorType>&& orthoVec) {
+    lanczosBase_.setOrthogonalizingVectors(std::move(orthoVec));
+    return *this;
+  }
+  const MatMulFunction& matrixMultiplication() const { return lanczosBase_.matrixMultiplication(); }
+  LanczosEigenSolver& setMatrixMultiplication(const MatMulFunction& matmul, Index height) {
+    lanczosBase_.setMatrixMultiplication(matmul, height);
+    return *this;
+  }
+  LanczosEigenSolver& setMatrixMultiplication(MatMulFunction&& matmul, Index height) {
+    lanczosBase_.setMatrixMultiplication(std::move(matmul), height);
+    return *this;
+  }
+  LanczosEigenSolver& setDeviceOperator(const std::shared_ptr<device::CsrOperator>& op) {
+    lanczosBase_.setDeviceOperator(op);
+    return *this;
+  }
+  LanczosEigenSolver& setDeviceContext(const std::shared_ptr<device::Context>& ctx) {
+    lanczosBase_.setDeviceContext(ctx);
+    return *this;
+  }
+  LanczosEigenSolver& setOrthogonalization(Orthogonalization o) {
+    lanczosBase_.setOrthogonalization(o);
+    return *this;
+  }
+  Index matrixHeight() const { return lanczosBase_.matrixHeight(); }
+  RealScalar eigenvalueShift() const { return lanczosBase_.eigenvalueShift(); }
+  LanczosEigenSolver& setEigenvalueShift(RealScalar eishift) {
+    lanczosBase_.setEigenvalueShift(eishift);
+    return *this;
+  }
+  Index reorthogonalizeInterval() const { return lanczosBase_.reorthogonalizeInterval(); }
+  LanczosEigenSolver& setReorthogonalizeInterval(Index reorthoInterval) {
+    lanczosBase_.setReorthogonalizeInterval(reorthoInterval);
+    return *this;
+  }
+  const VectorType& initialVector() const { return lanczosBase_.initialVector(); }
+  LanczosEigenSolver& setInitialVector(const VectorType& inivec) {
+    lanczosBase_.setInitialVector(inivec);
+    return *this;
+  }
+  LanczosEigenSolver& setInitialVector(VectorType&& inivec) {
+    lanczosBase_.setInitialVector(std::move(inivec));
+    return *this;
+  }
+  LanczosEigenSolver& setInitialVector() {
+    lanczosBase_.setInitialVector();
+    return *this;
+  }
+  RealScalar threshold() const { return lanczosBase_.threshold(); }
+  LanczosEigenSolver& setThreshold(RealScalar thre) {
+    lanczosBase_.setThreshold(thre);
+    return *this;
+  }
+  Index iterations() const { return lanczosBase_.iterations(); }
+  const std::vector<VectorType>& lanczosvectors() const { return lanczosBase_.lanczosvectors(); }
+  const std::vector<RealScalar>& alpha() const { return lanczosBase_.alpha(); }
+  const std::vector<RealScalar>& beta() const { return lanczosBase_.beta(); }
+
+  // ---- results (reference :643-647) ----
+  const RealVectorType& eigenvalues() const { return eigenvalues_; }
+  const MatrixType& eigenvectors() const { return eigenvectors_; }
+  const std::vector<std::string>& log() const { return log_; }
+  const std::map<Index, std::vector<RealScalar>>& convergenceLog() const { return convergenceLog_; }
+  // spectrum / eigenvectors of the current tridiagonal matrix (stand-in for es_tri())
+  const std::vector<RealScalar>& tridiagonalEigenvalues() const { return triValues_; }
+  RealMatrixType tridiagonalEigenvectors() const {
+    std::vector<double> vals, vecs;
+    const Index n = static_cast<Index>(lanczosBase_.alpha().size());
+    small_eigen::tridiagonal(lanczosBase_.alpha().data(), lanczosBase_.beta().data(), static_cast<int>(n), vals, &vecs);
+    RealMatrixType m(n, n);
+    std::copy(vecs.begin(), vecs.end(), m.data());
+    return m;
+  }
+
+  // Eigen-style status (not in the reference; derived from the events it logs)
+  ComputationInfo info() const { return info_; }
+
+  LanczosEigenSolver() { setAllSettingsDefault(); }
+
+  // defaults (reference :657-668); does not clear computed data
+  LanczosEigenSolver& setAllSettingsDefault() {
+    setMinIterations(1);
+    setMaxIterations(unlimited);
+    setTolerance(DefaultTolerance<RealScalar>::value());
+    setIndicesForConvergence(std::vector<Index>{0});
+    setMaxEigenvalues(unlimited);
+    setComputeEigenvectorsOn(true);
+    lanczosBase_.setAllSettingsDefault();
+    return *this;
+  }
+
+  // clears results, keeps settings (reference :675-682)
+  LanczosEigenSolver& clearComputedData() {
+    lanczosBase_.clearLanczosSteps();
+    eigenvalues_.resize(0);
+    eigenvectors_.resize(0, 0);
+    log_.clear();
+    convergenceLog_.clear();
+    triValues_.clear();
+    return *this;
+  }
+
+  LanczosEigenSolver& clear() {
+    clearComputedData();
+    setAllSettingsDefault();
+    return *this;
+  }
+
+  // resume from the current state, e.g. after raising maxIterations (reference :701-712)
+  Index continueToCompute() {
+    log_.push_back(headINFO() + "EigenSolver<ScalarType>::continueToCompute(...) was called");
+    if (lanczosBase_.lanczosvectorsSize() == 0) return compute();
+    const Index ret = mainCalculation_();
+    log_.push_back(headINFO() + "EigenSolver<ScalarType>::compute(...) finish computing");
+    return ret;
+  }
+
+  // (reference :717-736)
+  Index compute() {
+    log_.push_back(headINFO() + "EigenSolver<ScalarType>::compute(...) was called");
+    clearComputedData();
+    if (initialVector().size() != matrixHeight()) {
+      log_.push_back(headINFO() + "in compute(), initial_vector is empty or invalid, then set at random");
+      setInitialVector();
+    }
+    const Index ret = mainCalculation_();
+    log_.push_back(headINFO() + "EigenSolver<ScalarType>::compute(...) finish computing");
+    return ret;
+  }
+
+  Index hasERROR() const { return countHead_(headERROR()); }
+  Index hasWARN() const { return countHead_(headWARN()); }
+
+ protected:
+  Index countHead_(const std::string& head) const {
+    Index count = 0;
+    for (const auto& str : log_)
+      if (str.compare(0, head.size(), head) == 0) ++count;
+    return count;
+  }
+
+  void solveTridiagonal_() {
+    const auto& a = lanczosBase_.alpha();
+    const auto& b = lanczosBase_.beta();
+    small_eigen::tridiagonal(a.data(), b.data(), static_cast<int>(a.size()), triValues_, nullptr);
+  }
+
+  // Number of step calls that will certainly be executed from the current state: no exit
+  // test other than breakdown (which the GPU detects itself) can fire before
+  // iterations() reaches minIterations (reference :749-769).
+  Index certainCalls_() const {
+    const Index it = lanczosBase_.iterations();
+    Index calls = (lanczosBase_.lanczosvectorsSize() == 0 ? 1 : 0) + std::max<Index>(0, minIterations_ - it);
+    if (maxIterations_ != unlimited && maxIterations_ >= it)
+      calls = std::min(calls, (lanczosBase_.lanczosvectorsSize() == 0 ? 1 : 0) + (maxIterations_ - it));
+    calls = std::min(calls, std::max<Index>(0, matrixHeight() - lanczosBase_.lanczosvectorsSize()));
+    return calls;
+  }
+
+  // (reference :740-823)
+  Index mainCalculation_() {
+    info_ = Success;
+    if (matrixHeight() <= 0 || !lanczosBase_.hasOperator()) info_ = InvalidInput;
+    triValues_.clear();
+    solveTridiagonal_();
+    if (maxIterations_ != unlimited) lanczosBase_.reserveBasis(maxIterations_ + 1);  // m iterations -> m+1 vectors
+    lanczosBase_.prefetchLanczosSteps(certainCalls_());
+    bool initialVectorFailed = false;
+    while (true) {
+      updateConvergenceLog_();
+      if (initialVectorFailed) {
+        log_.push_back(headINFO() + "initial lanczosvector generation fail");
+        info_ = NumericalIssue;
+        break;
+      }
+      if (lanczosBase_.lanczosStepIsUtmost()) {
+        log_.push_back(headINFO() + "lanczos steps finished with threshold");
+        log_.push_back(headINFO() + "lanczos steps achieved full of Krylov subspace");
+        break;
+      }
+      if (lanczosBase_.iterations() >= minIterations()) {
+        if (lanczosBase_.iterations() == maxIterations()) {
+          log_.push_back(headWARN() + "lanczos steps achieved maxIterations");
+          info_ = NoConvergence;
+          break;
+        }
+        if (isConverged_()) {
+          log_.push_back(headINFO() + "lanczos steps converged with tolerance");
+          break;
+        }
+      }
+      const bool stepped = lanczosBase_.updateLanczosSteps();
+      if (lanczosBase_.lanczosvectorsSize() == 0) initialVectorFailed = true;
+      if (!stepped && !initialVectorFailed && !lanczosBase_.lanczosStepIsUtmost()) {
+        // matrixHeight <= 0 or no operator: the reference would spin forever here
+        log_.push_back(headERROR() + "lanczos step could not be executed (no operator or matrix height <= 0)");
+        info_ = InvalidInput;
+        break;
+      }
+      solveTridiagonal_();
+    }
+
+    // eigenvalues of the original matrix (shift removed), ascending, first maxEigenvalues only
+    Index eivalsize = static_cast<Index>(triValues_.size());
+    if (maxEigenvalues_ != unlimited && maxEigenvalues_ < eivalsize) eivalsize = maxEigenvalues_;
+    eigenvalues_.resize(eivalsize);
+    for (Index k = 0; k < eivalsize; ++k) eigenvalues_[k] = triValues_[static_cast<std::size_t>(k)] - lanczosBase_.eigenvalueShift();
+
+    if (computeEigenvectorsOn_) {
+      // X = V S, normalised, first non-zero entry made positive: one pass over V per 8 vectors, on the GPU
+      std::vector<double> vals, vecs;
+      const Index m = static_cast<Index>(lanczosBase_.alpha().size());
+      small_eigen::tridiagonal(lanczosBase_.alpha().data(), lanczosBase_.beta().data(), static_cast<int>(m), vals, &vecs);
+      eigenvectors_ = lanczosBase_.ritzVectors(vecs.data(), m, eivalsize);
+    } else {
+      eigenvectors_.resize(0, 0);
+    }
+    return 0;
+  }
+
+  // negative i counts from the end; -1 if out of range (reference :837-847)
+  static Index getFormalIndex(Index i, Index n) {
+    if (-n <= i && i < 0) return n - (-i - 1) % n - 1;
+    if (0 <= i && i < n) return i % n;
+    return -1;
+  }
+
+  // (reference :853-864)
+  void updateConvergenceLog_() {
+    for (const Index idx : indicesForConvergence_) {
+      const Index i = getFormalIndex(idx, static_cast<Index>(triValues_.size()));
+      if (i < 0) continue;
+      convergenceLog_[idx].push_back(triValues_[static_cast<std::size_t>(i)]);
+    }
+  }
+
+  // (reference :869-896)
+  bool isConverged_() const {
+    if (triValues_.size() < 2) return false;
+    const RealScalar scale = triValues_.front() - triValues_.back();
+    for (const Index idx : indicesForConvergence_) {
+      const auto itr = convergenceLog_.find(idx);
+      if (itr == convergenceLog_.end()) return false;
+      const auto& edge = itr->second;
+      if (edge.size() < 2) return false;
+      const RealScalar cur = edge[edge.size() - 1], old = edge[edge.size() - 2];
+      if (std::abs((cur - old) / scale) > tolerance_) return false;
+    }
+    return true;
+  }
+
+  Index minIterations_ = 1;
+  Index maxIterations_ = unlimited;
+  RealScalar tolerance_ = 1e-12;
+  std::vector<Index> indicesForConvergence_;
+  Index maxEigenvalues_ = unlimited;
+  bool computeEigenvectorsOn_ = true;
+
+  LanczosBase<Scalar> lanczosBase_;
+
+  RealVectorType eigenvalues_;
+  MatrixType eigenvectors_;
+  std::vector<std::string> log_;
+  std::vector<RealScalar> triValues_;
+  std::map<Index, std::vector<RealScalar>> convergenceLog_;
+  ComputationInfo info_ = Success;
+};
+
+template <class Scalar_>
+constexpr typename LanczosEigenSolver<Scalar_>::Index LanczosEigenSolver<Scalar_>::unlimited;
+
+}  // namespace EigenEx
+}  // namespace cmpt

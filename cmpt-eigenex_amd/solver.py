@@ -1,0 +1,223 @@
+"""ctypes view of libeigenex_solver.so: the flat C wrapper (csrc/solver_capi.cpp) around the
+header-only C++ solver classes LanczosEigenSolver<double> / ArnoldiEigenSolver<double>
+(cmpt-eigenex_amd/include/cmpt/eigen_ex/).  Plumbing for tests/ and bench.py: the Python
+side holds no algorithm, the method names mirror the C++ (= reference) names.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import capi
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libeigenex_solver.so")
+_dp = C.POINTER(C.c_double)
+_lp = C.POINTER(C.c_int64)
+_vp = C.c_void_p
+
+UNLIMITED = -1
+INFO = {0: "Success", 1: "NumericalIssue", 2: "NoConvergence", 3: "InvalidInput"}
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        capi.lib()  # libeigenex_hip.so first (RTLD_GLOBAL)
+        if not os.path.exists(LIB_PATH):
+            raise capi.EigenexError(f"{LIB_PATH} is missing: run `python -m cmpt_eigenex_amd.build`")
+        L = C.CDLL(LIB_PATH)
+        L.eigenex_solver_last_error.restype = C.c_char_p
+        L.eigenex_solver_default_start_vector.argtypes = [C.c_int64, _dp]
+        L.eigenex_solver_random_vector.argtypes = [C.c_uint32, C.c_int64, _dp]
+        L.eigenex_solver_tridiagonal_eigen.argtypes = [C.c_int, _dp, _dp, _dp, _dp]
+        L.eigenex_solver_hessenberg_eigen.argtypes = [C.c_int, _dp, _dp, _dp]
+        for kind in ("lanczos", "arnoldi"):
+            p = f"eigenex_{kind}_solver_"
+            getattr(L, p + "create").restype = _vp
+            getattr(L, p + "destroy").argtypes = [_vp]
+            getattr(L, p + "destroy").restype = None
+            getattr(L, p + "set_device_operator").argtypes = [_vp, _vp, _vp]
+            getattr(L, p + "set_host_operator").argtypes = [_vp, _vp, capi.MATVEC_FN, _vp, C.c_int64]
+            getattr(L, p + "set").argtypes = [_vp, C.c_char_p, C.c_double]
+            getattr(L, p + "set_indices_for_convergence").argtypes = [_vp, _lp, C.c_int]
+            getattr(L, p + "set_initial_vector").argtypes = [_vp, _dp, C.c_int64]
+            getattr(L, p + "set_orthogonalizing_vectors").argtypes = [_vp, _dp, C.c_int64, C.c_int]
+            getattr(L, p + "compute").argtypes = [_vp]
+            getattr(L, p + "continue").argtypes = [_vp]
+            getattr(L, p + "sizes").argtypes = [_vp, _lp]
+            getattr(L, p + "log_line").argtypes = [_vp, C.c_int64]
+            getattr(L, p + "log_line").restype = C.c_char_p
+        L.eigenex_lanczos_solver_get.argtypes = [_vp, _dp, _dp, _dp, _dp]
+        L.eigenex_lanczos_solver_lanczosvector.argtypes = [_vp, C.c_int64, _dp]
+        L.eigenex_lanczos_solver_convergence_log.argtypes = [_vp, C.c_int64, _dp, C.c_int64]
+        L.eigenex_lanczos_solver_convergence_log.restype = C.c_int64
+        L.eigenex_arnoldi_solver_get.argtypes = [_vp, _dp, _dp, _dp, _dp]
+        _LIB = L
+    return _LIB
+
+
+def _chk(rc):
+    if rc != 0:
+        raise capi.EigenexError(lib().eigenex_solver_last_error().decode(errors="replace"))
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def default_start_vector(n: int) -> np.ndarray:
+    out = np.empty(n)
+    _chk(lib().eigenex_solver_default_start_vector(n, _d(out)))
+    return out
+
+
+def random_vector(seed: int, n: int) -> np.ndarray:
+    out = np.empty(n)
+    _chk(lib().eigenex_solver_random_vector(seed, n, _d(out)))
+    return out
+
+
+def tridiagonal_eigen(diag, sub, vectors=True):
+    diag = np.ascontiguousarray(diag, np.float64)
+    n = diag.size
+    sub = np.ascontiguousarray(np.concatenate([np.asarray(sub, np.float64), np.zeros(1)]))
+    vals = np.empty(n)
+    vecs = np.empty((n, n)) if vectors else None
+    _chk(lib().eigenex_solver_tridiagonal_eigen(n, _d(diag), _d(sub), _d(vals), _d(vecs) if vectors else None))
+    return vals, (vecs.T.copy() if vectors else None)  # column-major -> [row, col]
+
+
+def hessenberg_eigen(H, vectors=True):
+    H = np.asfortranarray(H, np.complex128)
+    n = H.shape[0]
+    vals = np.empty(n, np.complex128)
+    vecs = np.empty((n, n), np.complex128, order="F") if vectors else None
+    _chk(lib().eigenex_solver_hessenberg_eigen(n, H.ctypes.data_as(_dp), vals.ctypes.data_as(_dp),
+                                               vecs.ctypes.data_as(_dp) if vectors else None))
+    return vals, vecs
+
+
+class _SolverBase:
+    _kind = ""
+
+    def __init__(self):
+        self._L = lib()
+        self.h = _vp(getattr(self._L, f"eigenex_{self._kind}_solver_create")())
+        if not self.h:
+            raise capi.EigenexError("solver create failed")
+        self._keep = []
+
+    def _f(self, name):
+        return getattr(self._L, f"eigenex_{self._kind}_solver_{name}")
+
+    def setDeviceOperator(self, csr: capi.Csr):
+        self._keep.append(csr)
+        _chk(self._f("set_device_operator")(self.h, csr.ctx.h, csr.h))
+        return self
+
+    def setMatrixMultiplication(self, fn, height: int, ctx: capi.Context | None = None):
+        """fn(x: ndarray) -> ndarray, the reference's MatMulFunction (called on the host)."""
+        n = height
+
+        def tramp(pin, pout, _user):
+            x = np.ctypeslib.as_array(pin, shape=(n,))
+            y = np.ctypeslib.as_array(pout, shape=(n,))
+            y[:] = fn(x)
+
+        cb = capi.MATVEC_FN(tramp)
+        self._keep += [cb, ctx]
+        _chk(self._f("set_host_operator")(self.h, ctx.h if ctx else None, cb, None, height))
+        return self
+
+    def set(self, **kw):
+        for k, v in kw.items():
+            if k == "indicesForConvergence":
+                a = np.ascontiguousarray(v, np.int64)
+                _chk(self._f("set_indices_for_convergence")(self.h, a.ctypes.data_as(_lp), a.size))
+            elif k == "initialVector":
+                a = np.ascontiguousarray(v, np.float64)
+                _chk(self._f("set_initial_vector")(self.h, _d(a), a.size))
+            elif k == "orthogonalizingVectors":
+                a = np.ascontiguousarray(np.stack(v), np.float64) if len(v) else np.zeros((0, 1))
+                _chk(self._f("set_orthogonalizing_vectors")(self.h, _d(a), a.shape[1], a.shape[0]))
+            else:
+                _chk(self._f("set")(self.h, k.encode(), float(v)))
+        return self
+
+    def compute(self):
+        _chk(self._f("compute")(self.h))
+        return self
+
+    def continueToCompute(self):
+        _chk(self._f("continue")(self.h))
+        return self
+
+    def log(self):
+        n = self._sizes()["nlog"]
+        return [self._f("log_line")(self.h, i).decode() for i in range(n)]
+
+    def close(self):
+        if self.h:
+            self._f("destroy")(self.h)
+            self.h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class LanczosEigenSolver(_SolverBase):
+    _kind = "lanczos"
+    _names = ("iterations", "nvec", "nalpha", "nbeta", "neig", "vec_rows", "vec_cols", "nlog", "info", "hasWARN", "hasERROR")
+
+    def _sizes(self):
+        out = np.zeros(len(self._names), np.int64)
+        _chk(self._f("sizes")(self.h, out.ctypes.data_as(_lp)))
+        return dict(zip(self._names, (int(x) for x in out)))
+
+    def results(self):
+        s = self._sizes()
+        alpha, beta, ev = np.zeros(s["nalpha"]), np.zeros(s["nbeta"]), np.zeros(s["neig"])
+        X = np.zeros((s["vec_rows"], s["vec_cols"]), order="F")
+        _chk(self._L.eigenex_lanczos_solver_get(self.h, _d(alpha), _d(beta), _d(ev), _d(X) if X.size else None))
+        s.update(alpha=alpha, beta=beta, eigenvalues=ev, eigenvectors=X, info_name=INFO[s["info"]])
+        return s
+
+    def lanczosvector(self, k: int, n_rows: int):
+        out = np.empty(n_rows)
+        _chk(self._L.eigenex_lanczos_solver_lanczosvector(self.h, k, _d(out)))
+        return out
+
+    def convergenceLog(self, index: int):
+        buf = np.zeros(1 << 16)
+        n = self._L.eigenex_lanczos_solver_convergence_log(self.h, index, _d(buf), buf.size)
+        return buf[:n].copy()
+
+
+class ArnoldiEigenSolver(_SolverBase):
+    _kind = "arnoldi"
+    _names = ("iterations", "nvec", "hess_rows", "neig", "vec_rows", "vec_cols", "nlog", "info", "hasWARN", "hasERROR")
+
+    def _sizes(self):
+        out = np.zeros(len(self._names), np.int64)
+        _chk(self._f("sizes")(self.h, out.ctypes.data_as(_lp)))
+        return dict(zip(self._names, (int(x) for x in out)))
+
+    def results(self):
+        s = self._sizes()
+        m = s["hess_rows"]
+        H = np.zeros((m, m), order="F")
+        ev = np.zeros(s["neig"], np.complex128)
+        X = np.zeros((s["vec_rows"], s["vec_cols"]), np.complex128, order="F")
+        res = C.c_double()
+        _chk(self._L.eigenex_arnoldi_solver_get(self.h, _d(H) if H.size else None, ev.ctypes.data_as(_dp),
+                                                X.ctypes.data_as(_dp) if X.size else None, C.byref(res)))
+        s.update(hessenberg=H, eigenvalues=ev, eigenvectors=X, residue=res.value, info_name=INFO[s["info"]])
+        return s

@@ -132,6 +132,10 @@ int eigenex_basis_set_host_operator(eigenex_basis_t b, eigenex_matvec_fn fn, voi
 /* settings of LanczosBase/ArnoldiBase that the kernels need (lanczos.hpp:155-159) */
 int eigenex_basis_configure(eigenex_basis_t b, double eigenvalue_shift, double threshold,
                             int64_t reorthogonalize_interval, int ortho_mode);
+/* grow the basis slab to hold at least `capacity` vectors, keeping the state (the reference's
+ * std::vector<VectorType>::push_back never runs out: lanczos.hpp:402, arnoldi.hpp:364) */
+int eigenex_basis_reserve(eigenex_basis_t b, int capacity);
+int eigenex_basis_capacity(eigenex_basis_t b, int* capacity);
 /* clearLanczosSteps()/clearArnoldiSteps(): forget vectors and coefficients, keep settings */
 int eigenex_basis_clear(eigenex_basis_t b);
 
@@ -182,6 +186,11 @@ int eigenex_arnoldi_state(eigenex_basis_t b, eigenex_state_t* st, double* hess, 
  * (lanczos.hpp:798-816).  X is returned to the host (rows owned by this context),
  * leading dimension ldx. */
 int eigenex_ritz_vectors(eigenex_basis_t b, int nvec, int nev, const double* S, int lds, double* X, int64_t ldx);
+/* complex coefficients (Arnoldi, arnoldi.hpp:841-865): S_re/S_im column-major nvec x nev (leading dimension lds);
+ * X receives interleaved (re,im) pairs, i.e. std::complex<double>[ldx * nev]; each column is normalised and divided by
+ * the phase z/|z| of its first non-zero entry. */
+int eigenex_ritz_vectors_complex(eigenex_basis_t b, int nvec, int nev, const double* S_re, const double* S_im, int lds,
+                                 double* X_interleaved, int64_t ldx);
 
 #ifdef __cplusplus
 }

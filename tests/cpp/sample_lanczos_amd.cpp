@@ -1,0 +1,67 @@
+// C++ drop-in check: a user program written against the reference's solver API
+// (the call sequence of the reference's smallest sample: operator lambda,
+// setMatrixMultiplication, setTolerance, setMaxIterations, compute, eigenvalues,
+// eigenvectors, log), compiled against the header-only classes of
+// cmpt-eigenex_amd/include.  Prints a small JSON document that the pytest
+// wrapper checks against the sample's analytic answer (tests/golden/reference_samples.json).
+// Also runs the same solve with a device-resident CSR operator.
+#include <cstdio>
+#include <vector>
+
+#include "cmpt/eigen_ex/arnoldi.hpp"
+#include "cmpt/eigen_ex/lanczos.hpp"
+
+int main() {
+  using namespace cmpt::EigenEx;
+  const int n = 3;
+  const double H[9] = {1.0, 0.5, 0.0, 0.5, 2.0, 0.5, 0.0, 0.5, 3.0};
+  auto matmul = [&H, n](const double* in, double* out) {
+    for (int r = 0; r < n; ++r) {
+      double s = 0.0;
+      for (int c = 0; c < n; ++c) s += H[r * n + c] * in[c];
+      out[r] = s;
+    }
+  };
+  try {
+    LanczosEigenSolver<double> lanczos;
+    lanczos.setMatrixMultiplication(matmul, n).setTolerance(1.0e-5).setMaxIterations(100);
+    lanczos.compute();
+    std::printf("{\"host_operator\": {\"eigenvalues\": [");
+    for (Index i = 0; i < lanczos.eigenvalues().size(); ++i) std::printf("%s%.17g", i ? ", " : "", lanczos.eigenvalues()[i]);
+    std::printf("], \"eigenvectors\": [");
+    for (Index c = 0; c < lanczos.eigenvectors().cols(); ++c)
+      for (Index r = 0; r < n; ++r) std::printf("%s%.17g", (c || r) ? ", " : "", lanczos.eigenvectors()(r, c));
+    std::printf("], \"iterations\": %ld, \"info\": %d, \"log\": [", (long)lanczos.iterations(), (int)lanczos.info());
+    for (std::size_t i = 0; i < lanczos.log().size(); ++i) std::printf("%s\"%s\"", i ? ", " : "", lanczos.log()[i].c_str());
+    std::printf("]}, ");
+
+    // same matrix as a device-resident CSR operator
+    std::vector<std::int32_t> rowptr = {0, 2, 5, 7}, col = {0, 1, 0, 1, 2, 1, 2};
+    std::vector<double> val = {1.0, 0.5, 0.5, 2.0, 0.5, 0.5, 3.0};
+    auto ctx = std::make_shared<device::Context>(0);
+    auto op = std::make_shared<device::CsrOperator>(ctx, n, 0, n, rowptr.data(), col.data(), val.data());
+    LanczosEigenSolver<double> dev;
+    dev.setDeviceOperator(op).setTolerance(1.0e-5).setMaxIterations(100);
+    dev.compute();
+    std::printf("\"device_operator\": {\"eigenvalues\": [");
+    for (Index i = 0; i < dev.eigenvalues().size(); ++i) std::printf("%s%.17g", i ? ", " : "", dev.eigenvalues()[i]);
+    std::printf("], \"subspace\": %ld}, ", (long)dev.lanczosvectors().size());
+
+    // Arnoldi on the same operator: full Krylov space, A P = P D
+    ArnoldiEigenSolver<double> ar;
+    ar.setDeviceOperator(op).setMaxIterations(3).setMinIterations(3);
+    ar.compute();
+    double worst = 0.0;
+    for (Index c = 0; c < ar.eigenvectors().cols(); ++c)
+      for (int r = 0; r < n; ++r) {
+        std::complex<double> ap = 0.0;
+        for (int k = 0; k < n; ++k) ap += H[r * n + k] * ar.eigenvectors()(k, c);
+        worst = std::max(worst, std::abs(ap - ar.eigenvalues()[c] * ar.eigenvectors()(r, c)));
+      }
+    std::printf("\"arnoldi\": {\"n\": %ld, \"max_residual\": %.3g}}\n", (long)ar.eigenvalues().size(), worst);
+  } catch (const std::exception& e) {
+    std::printf("{\"error\": \"%s\"}\n", e.what());
+    return 1;
+  }
+  return 0;
+}

@@ -1,0 +1,328 @@
+"""GPU parity tests, solver level: the header-only C++ classes
+LanczosEigenSolver<double> / ArnoldiEigenSolver<double> (driven through
+libeigenex_solver.so, and once as a compiled C++ program) against the oracle's
+restatement of the reference front-ends (oracle/krylov_oracle.py), same inputs.
+
+Tolerance: Ritz values 1e-10 relative to the spectral scale (north star); log
+lines must match the reference's strings verbatim.
+"""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import cref
+from oracle import krylov_oracle as ko
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from cmpt_eigenex_amd import capi, solver
+
+    assert capi.device_count() >= 1
+    return capi, solver
+
+
+def _assert_same_multiset(a, b, atol):
+    """complex values equal as multisets (greedy nearest matching): conjugate pairs tie in modulus
+    and their order is unspecified (std::sort, arnoldi.hpp:813-819)."""
+    a, b = list(np.asarray(a)), list(np.asarray(b))
+    assert len(a) == len(b)
+    for x in a:
+        k = int(np.argmin([abs(x - y) for y in b]))
+        assert abs(x - b[k]) <= atol, (x, b[k])
+        b.pop(k)
+
+
+def _oracle_lanczos(matmul, n, init, **kw):
+    es = ko.LanczosEigenSolverOracle()
+    es.set_matrix_multiplication(matmul, n)
+    es.base.initial_vector = init
+    for k, v in kw.items():
+        if hasattr(es, k):
+            setattr(es, k, v)
+        else:
+            setattr(es.base, k, v)
+    es.compute()
+    return es
+
+
+def test_cpp_program_against_reference_sample(golden_dir, tmp_path):
+    """A C++ user program on the header-only API (the reference's smallest sample)."""
+    exe = str(tmp_path / "sample_amd")
+    lib = os.path.join(ROOT, "cmpt-eigenex_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-I", os.path.join(ROOT, "include"), "-I",
+                           os.path.join(ROOT, "cmpt-eigenex_amd", "include"),
+                           os.path.join(ROOT, "tests", "cpp", "sample_lanczos_amd.cpp"), "-o", exe, "-L", lib,
+                           "-leigenex_hip", "-Wl,-rpath," + lib])
+    out = json.loads(subprocess.check_output([exe]).decode())
+    gold = json.load(open(os.path.join(golden_dir, "reference_samples.json")))["sample_lanczos1"]
+    for key in ("host_operator", "device_operator"):
+        np.testing.assert_allclose(out[key]["eigenvalues"], gold["eigenvalues"], rtol=0, atol=1e-13)
+    ho = out["host_operator"]
+    assert ho["iterations"] == 2 and ho["info"] == 0
+    assert ho["log"][-3:] == [
+        "INFO      lanczos steps finished with threshold",
+        "INFO      lanczos steps achieved full of Krylov subspace",
+        "INFO      EigenSolver<ScalarType>::compute(...) finish computing",
+    ]
+    X = np.array(ho["eigenvectors"]).reshape(3, 3).T
+    H = np.array(gold["matrix_rowmajor"]).reshape(3, 3)
+    np.testing.assert_allclose(H @ X, X * np.array(gold["eigenvalues"]), atol=1e-12)
+    assert np.all(X[0] > 0)
+    assert out["device_operator"]["subspace"] == 3
+    assert out["arnoldi"]["n"] == 3 and out["arnoldi"]["max_residual"] < 1e-12
+
+
+def test_lanczos1_sample_log_matches_oracle(mods, golden_dir):
+    capi, solver = mods
+    gold = json.load(open(os.path.join(golden_dir, "reference_samples.json")))["sample_lanczos1"]
+    H = np.array(gold["matrix_rowmajor"]).reshape(3, 3)
+    ref = ko.LanczosEigenSolverOracle()
+    ref.set_matrix_multiplication(lambda x: H @ x, 3)
+    ref.tolerance, ref.max_iterations = gold["tolerance"], gold["max_iterations"]
+    ref.compute()  # default start vector: libstdc++ restatement in the oracle
+    es = solver.LanczosEigenSolver()
+    es.setMatrixMultiplication(lambda x: H @ x, 3).set(tolerance=gold["tolerance"], maxIterations=gold["max_iterations"])
+    es.compute()
+    r = es.results()
+    assert es.log() == ref.log
+    np.testing.assert_allclose(r["eigenvalues"], ref.eigenvalues, atol=1e-14)
+    np.testing.assert_allclose(r["eigenvectors"], ref.eigenvectors, atol=1e-13)
+    np.testing.assert_allclose(r["alpha"], ref.base.alpha, atol=1e-14)
+
+
+def test_config1_dense512_lowest5(mods):
+    """BASELINE config 1: dense 512x512 symmetric, lowest-5 eigenpairs, std::function operator."""
+    capi, solver = mods
+    n = 512
+    rng = np.random.default_rng(42)
+    R = rng.standard_normal((n, n))
+    A = (R + R.T) / 2
+    init = solver.default_start_vector(n)
+    idx = [0, 1, 2, 3, 4]
+    ref = _oracle_lanczos(lambda x: A @ x, n, init, tolerance=1e-10, indices_for_convergence=idx, max_eigenvalues=5,
+                          max_iterations=600)
+    es = solver.LanczosEigenSolver()
+    es.setMatrixMultiplication(lambda x: A @ x, n).set(tolerance=1e-10, indicesForConvergence=idx, maxEigenvalues=5,
+                                                       maxIterations=600)
+    es.compute()
+    r = es.results()
+    scale = abs(ref._tri_vals[0] - ref._tri_vals[-1])
+    assert abs(r["iterations"] - ref.base.iterations) <= 1
+    assert r["neig"] == 5 and r["info_name"] == "Success"
+    np.testing.assert_allclose(r["eigenvalues"], ref.eigenvalues, rtol=0, atol=1e-9 * scale)
+    lam = np.linalg.eigvalsh(A)[:5]
+    np.testing.assert_allclose(r["eigenvalues"], lam, rtol=0, atol=1e-7 * scale)
+    X = r["eigenvectors"]
+    assert X.shape == (n, 5)
+    for e in range(5):
+        assert 1 - abs(X[:, e] @ ref.eigenvectors[:, e]) < 1e-8
+        assert X[np.flatnonzero(X[:, e])[0], e] > 0
+    assert es.log()[-2] == "INFO      lanczos steps converged with tolerance"
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_config2_laplacian_fixed_iterations(mods, mode):
+    """BASELINE config 2 at a size the oracle finishes quickly: 24^3 Laplacian, m = 50."""
+    capi, solver = mods
+    n, m = 24, 50
+    N = n ** 3
+    rowptr, col, val = cref.laplacian3d(n)
+    init = solver.default_start_vector(N)
+    c = cref.CLanczos(rowptr, col, val, init, cap=m + 2)
+    assert c.run(m + 1) == m + 1
+    th_ref = ko.tridiagonal_eigh(c.alpha, c.beta, vectors=False)[0]
+    ctx = capi.Context()
+    A = capi.Csr.laplacian3d(ctx, n)
+    es = solver.LanczosEigenSolver()
+    es.setDeviceOperator(A).set(minIterations=m, maxIterations=m, computeEigenvectorsOn=0, orthogonalization=mode,
+                                initialVector=init)
+    es.compute()
+    r = es.results()
+    assert (r["iterations"], r["nvec"], r["nalpha"], r["nbeta"]) == (m, m + 1, m + 1, m)
+    assert r["info_name"] == "NoConvergence" and r["hasWARN"] == 1 and r["vec_cols"] == 0
+    assert es.log()[-2] == "WARN      lanczos steps achieved maxIterations"
+    np.testing.assert_allclose(r["alpha"], c.alpha, atol=1e-12)
+    np.testing.assert_allclose(r["beta"], c.beta, atol=1e-12)
+    np.testing.assert_allclose(r["eigenvalues"], th_ref, rtol=1e-10)
+    # convergenceLog: Ritz value 0 after every step, m+2 entries? (one per loop pass that had >= 1 Ritz value)
+    cl = es.convergenceLog(0)
+    assert cl.size == m + 1
+    assert abs(cl[-1] - th_ref[0]) < 1e-10
+    ctx.close()
+
+
+def test_convergence_driven_run_and_continue(mods):
+    capi, solver = mods
+    n = 12
+    N = n ** 3
+    rowptr, col, val = cref.laplacian3d(n)
+    init = np.random.default_rng(3).standard_normal(N)
+    matmul = ko.csr_matmul(rowptr, col, val)
+    ref = _oracle_lanczos(matmul, N, init, tolerance=1e-9, indices_for_convergence=[0, -1], max_eigenvalues=3)
+    ctx = capi.Context()
+    A = capi.Csr.upload(ctx, N, rowptr, col, val)
+    es = solver.LanczosEigenSolver()
+    es.setDeviceOperator(A).set(tolerance=1e-9, indicesForConvergence=[0, -1], maxEigenvalues=3, initialVector=init)
+    es.compute()
+    r = es.results()
+    assert abs(r["iterations"] - ref.base.iterations) <= 1
+    assert es.log() == ref.log
+    np.testing.assert_allclose(r["eigenvalues"], ref.eigenvalues, rtol=1e-9)
+    if r["iterations"] == ref.base.iterations:
+        np.testing.assert_allclose(es.convergenceLog(0), ref.convergence_log[0], rtol=1e-10)
+        np.testing.assert_allclose(es.convergenceLog(-1), ref.convergence_log[-1], rtol=1e-10)
+    lam = ko.laplacian3d_eigenvalues(n, 1)[0]
+    assert abs(r["eigenvalues"][0] - lam) < 1e-6
+    # continueToCompute after raising the iteration cap == one uninterrupted run
+    es2 = solver.LanczosEigenSolver()
+    es2.setDeviceOperator(A).set(minIterations=10, maxIterations=10, initialVector=init, computeEigenvectorsOn=0)
+    es2.compute()
+    assert es2.results()["iterations"] == 10
+    es2.set(minIterations=25, maxIterations=25)
+    es2.continueToCompute()
+    r2 = es2.results()
+    es3 = solver.LanczosEigenSolver()
+    es3.setDeviceOperator(A).set(minIterations=25, maxIterations=25, initialVector=init, computeEigenvectorsOn=0)
+    es3.compute()
+    r3 = es3.results()
+    assert r2["iterations"] == 25
+    np.testing.assert_array_equal(r2["alpha"], r3["alpha"])
+    np.testing.assert_array_equal(r2["beta"], r3["beta"])
+    # compute() erases its own first line (log_.clear() in clearComputedData, lanczos.hpp:679, :719-721)
+    assert es2.log()[:3] == ["WARN      lanczos steps achieved maxIterations",
+                             "INFO      EigenSolver<ScalarType>::compute(...) finish computing",
+                             "INFO      EigenSolver<ScalarType>::continueToCompute(...) was called"]
+    ctx.close()
+
+
+def test_failure_paths_and_info(mods):
+    capi, solver = mods
+    rowptr = np.arange(5, dtype=np.int32)
+    col = np.arange(4, dtype=np.int32)
+    val = np.array([1.0, 2.0, 3.0, 4.0])
+    ctx = capi.Context()
+    A = capi.Csr.upload(ctx, 4, rowptr, col, val)
+    # zero start vector (lanczos.hpp:316-318, :750-753)
+    ref = _oracle_lanczos(ko.csr_matmul(rowptr, col, val), 4, np.zeros(4))
+    es = solver.LanczosEigenSolver()
+    es.setDeviceOperator(A).set(initialVector=np.zeros(4))
+    es.compute()
+    assert es.log() == ref.log and es.log()[-2] == "INFO      initial lanczosvector generation fail"
+    r = es.results()
+    assert r["info_name"] == "NumericalIssue" and r["neig"] == 0 and r["nvec"] == 0
+    # breakdown in a 2-dimensional invariant subspace (lanczos.hpp:433-437)
+    init = np.array([1.0, 1.0, 0.0, 0.0])
+    ref = _oracle_lanczos(ko.csr_matmul(rowptr, col, val), 4, init)
+    es = solver.LanczosEigenSolver()
+    es.setDeviceOperator(A).set(initialVector=init)
+    es.compute()
+    r = es.results()
+    assert es.log() == ref.log
+    assert (r["nvec"], r["nalpha"], r["nbeta"]) == (2, 2, 2) and r["info_name"] == "Success"
+    np.testing.assert_allclose(r["eigenvalues"], [1.0, 2.0], atol=1e-14)
+    np.testing.assert_allclose(np.abs(r["eigenvectors"]), np.abs(ref.eigenvectors), atol=1e-14)
+    ctx.close()
+
+
+def test_locking_with_orthogonalizing_vectors(mods):
+    """setOrthogonalizingVectors deflates converged vectors (lanczos.hpp:169-176, :312-314, :421-425)."""
+    capi, solver = mods
+    n = 10
+    N = n ** 3
+    rowptr, col, val = cref.laplacian3d(n)
+    init = np.random.default_rng(8).standard_normal(N)
+    ctx = capi.Context()
+    A = capi.Csr.upload(ctx, N, rowptr, col, val)
+    es = solver.LanczosEigenSolver()
+    es.setDeviceOperator(A).set(tolerance=1e-13, maxEigenvalues=1, initialVector=init, minIterations=150, maxIterations=400)
+    es.compute()
+    r = es.results()
+    x0 = r["eigenvectors"][:, 0].copy()
+    lam = ko.laplacian3d_eigenvalues(n, 4)
+    assert abs(r["eigenvalues"][0] - lam[0]) < 1e-10
+    ref = _oracle_lanczos(ko.csr_matmul(rowptr, col, val), N, init, orthogonalizing_vectors=[x0], tolerance=1e-10,
+                          max_eigenvalues=1, max_iterations=300)
+    es = solver.LanczosEigenSolver()
+    es.setDeviceOperator(A).set(tolerance=1e-10, maxEigenvalues=1, initialVector=init, maxIterations=300,
+                                orthogonalizingVectors=[x0])
+    es.compute()
+    r = es.results()
+    assert abs(r["iterations"] - ref.base.iterations) <= 1
+    assert abs(r["eigenvalues"][0] - ref.eigenvalues[0]) < 1e-9
+    assert abs(r["eigenvalues"][0] - lam[1]) < 1e-6  # the locked pair is gone: next eigenvalue
+    assert abs(x0 @ r["eigenvectors"][:, 0]) < 1e-8
+    ctx.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_config3_arnoldi_random_csr(mods, mode):
+    """BASELINE config 3 at a size the oracle finishes quickly: random non-symmetric CSR, Arnoldi m = 40."""
+    capi, solver = mods
+    rng = np.random.default_rng(12345)
+    N, per, m = 4000, 32, 40
+    col = np.stack([np.sort(rng.choice(N, per, replace=False)) for _ in range(N)]).astype(np.int32).ravel()
+    rowptr = (np.arange(N + 1) * per).astype(np.int32)
+    val = rng.uniform(-1, 1, N * per)
+    init = solver.default_start_vector(N)
+    matmul = ko.csr_matmul(rowptr, col, val)
+    ref = ko.ArnoldiEigenSolverOracle()
+    ref.set_matrix_multiplication(matmul, N)
+    ref.base.initial_vector = init
+    ref.min_iterations = ref.max_iterations = m
+    ref.max_eigenvalues = 6
+    ref.compute()
+    ctx = capi.Context()
+    A = capi.Csr.upload(ctx, N, rowptr, col, val)
+    es = solver.ArnoldiEigenSolver()
+    es.setDeviceOperator(A).set(minIterations=m, maxIterations=m, maxEigenvalues=6, initialVector=init, orthogonalization=mode)
+    es.compute()
+    r = es.results()
+    assert (r["iterations"], r["nvec"], r["hess_rows"]) == (m, m, m)
+    assert es.log() == ref.log and r["info_name"] == "NoConvergence"
+    np.testing.assert_allclose(r["hessenberg"], ref.hessenberg_matrix, atol=1e-11)
+    assert abs(r["residue"] - ref.base.residue) < 1e-11
+    # Ritz values: same multiset (conjugate pairs tie in modulus, order inside a pair is unspecified)
+    scale = np.abs(ref.eigenvalues).max()
+    _assert_same_multiset(r["eigenvalues"], ref.eigenvalues, 1e-10 * scale)
+    assert np.all(np.diff(np.abs(r["eigenvalues"])) <= 1e-12 * scale)  # descending modulus
+    # Ritz vectors: unit norm, first entry real positive, residual equal to the oracle's
+    X = r["eigenvectors"]
+    np.testing.assert_allclose(np.linalg.norm(X, axis=0), 1.0, atol=1e-12)
+    assert np.all(np.abs(X[0].imag) < 1e-12) and np.all(X[0].real > 0)
+    import scipy.sparse as sp
+
+    Asp = sp.csr_matrix((val, col, rowptr), shape=(N, N))
+    for e in range(6):
+        k = int(np.argmin(np.abs(ref.eigenvalues - r["eigenvalues"][e])))
+        res = np.linalg.norm(Asp @ X[:, e] - r["eigenvalues"][e] * X[:, e])
+        res_ref = np.linalg.norm(Asp @ ref.eigenvectors[:, k] - ref.eigenvalues[k] * ref.eigenvectors[:, k])
+        assert abs(res - res_ref) < 1e-8
+        assert 1 - abs(np.vdot(X[:, e], ref.eigenvectors[:, k])) < 1e-8
+    ctx.close()
+
+
+def test_arnoldi_sample_property_full_space(mods):
+    """reference sample_arnoldi.cpp:46-53: A P = P D exactly when m == n (real operator here)."""
+    capi, solver = mods
+    rng = np.random.default_rng(0)
+    n = 50
+    Ad = rng.uniform(-1, 1, (n, n))
+    es = solver.ArnoldiEigenSolver()
+    es.setMatrixMultiplication(lambda x: Ad @ x, n).set(minIterations=n, maxIterations=n, tolerance=1e-14, maxEigenvalues=2)
+    es.compute()
+    r = es.results()
+    P, D = r["eigenvectors"], r["eigenvalues"]
+    assert P.shape == (n, 2) and r["iterations"] == n
+    assert np.abs(Ad @ P - P * D).max() < 1e-10
+    lam = np.linalg.eigvals(Ad)
+    lam = lam[np.argsort(-np.abs(lam), kind="stable")][:2]
+    _assert_same_multiset(D, lam, 1e-10)
+    assert es.log()[-3:-1] == ["INFO      arnoldi steps finished with threshold",
+                               "INFO      arnoldi steps achieved full of Krylov subspace"]
