@@ -19,6 +19,7 @@ ORTHO_BATCHED = 0
 ORTHO_SEQUENTIAL = 1
 VEC_V = -1
 VEC_W = -2
+VEC_START = -3
 K_SPMV, K_DOTS, K_UPDATE, K_SMALL, K_COMM, K_RITZ = range(6)
 
 
@@ -74,6 +75,10 @@ SIGNATURES = {
     "eigenex_basis_clear": (C.c_int, [_vp]),
     "eigenex_vec_upload": (C.c_int, [_vp, C.c_int, _dp]),
     "eigenex_vec_download": (C.c_int, [_vp, C.c_int, _dp]),
+    "eigenex_vec_copy": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "eigenex_basis_reserve": (C.c_int, [_vp, C.c_int]),
+    "eigenex_basis_capacity": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "eigenex_ritz_vectors_complex": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, C.c_int, _dp, C.c_int64]),
     "eigenex_apply": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, _dp]),
     "eigenex_dots": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
     "eigenex_update": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp]),
@@ -261,6 +266,13 @@ class Basis:
         x = np.ascontiguousarray(x, np.float64)
         assert x.size == self.n_rows
         _chk(lib().eigenex_vec_upload(self.h, ref, _d(x)))
+
+    def copy(self, dst_ref: int, src_ref: int):
+        _chk(lib().eigenex_vec_copy(self.h, dst_ref, src_ref))
+
+    def reserve(self, capacity: int):
+        _chk(lib().eigenex_basis_reserve(self.h, capacity))
+        self.capacity = max(self.capacity, capacity)
 
     def download(self, ref: int):
         x = np.empty(self.n_rows, np.float64)

@@ -171,7 +171,7 @@ struct BasisShard {
   int gshard = 0;
   int64_t rb = 0, nloc = 0, ldv = 0, nhalo = 0;
   CsrShard* csr = nullptr;
-  double *V = nullptr, *Q = nullptr, *v = nullptr, *w = nullptr;
+  double *V = nullptr, *Q = nullptr, *v = nullptr, *w = nullptr, *start = nullptr;
   double *partials = nullptr, *hbuf = nullptr, *alpha = nullptr, *beta = nullptr, *H = nullptr;
   double* X = nullptr;  // Ritz vector scratch (ldv x 8), lazy
   Ctrl* ctrl = nullptr;
@@ -430,6 +430,7 @@ double* vec_ptr(BasisShard& s, int cap, int nq, int ref) {
   if (ref >= 0) return ref < cap ? s.V + (int64_t)ref * s.ldv : nullptr;
   if (ref == EIGENEX_VEC_V) return s.v;
   if (ref == EIGENEX_VEC_W) return s.w;
+  if (ref == EIGENEX_VEC_START) return s.start;
   const int q = -16 - ref;
   if (q >= 0 && q < nq) return s.Q + (int64_t)q * s.ldv;
   return nullptr;
@@ -962,7 +963,7 @@ int eigenex_basis_destroy(eigenex_basis_t b) {
   (void)hipSetDevice(b->ctx->device);
   (void)hipStreamSynchronize(b->ctx->stream);
   for (auto& s : b->sh) {
-    for (void* p : {(void*)s.V, (void*)s.Q, (void*)s.v, (void*)s.w, (void*)s.partials, (void*)s.hbuf, (void*)s.alpha,
+    for (void* p : {(void*)s.V, (void*)s.Q, (void*)s.v, (void*)s.w, (void*)s.start, (void*)s.partials, (void*)s.hbuf, (void*)s.alpha,
                     (void*)s.beta, (void*)s.H, (void*)s.X, (void*)s.ctrl, (void*)s.ctrl_zero})
       if (p) (void)hipFree(p);
   }
@@ -1009,6 +1010,8 @@ int eigenex_basis_create(eigenex_context_t c, eigenex_csr_t csr, int64_t n_globa
       }
       HIPCHK(hipMalloc(&s.v, vbytes));
       HIPCHK(hipMemsetAsync(s.v, 0, vbytes, c->stream));
+      HIPCHK(hipMalloc(&s.start, vbytes));
+      HIPCHK(hipMemsetAsync(s.start, 0, vbytes, c->stream));
       HIPCHK(hipMalloc(&s.w, sizeof(double) * (size_t)(s.ldv + s.nhalo + 8)));
       HIPCHK(hipMemsetAsync(s.w, 0, sizeof(double) * (size_t)(s.ldv + s.nhalo + 8), c->stream));
       s.g_vec = grid_for_tiles((s.nloc + kTileRows - 1) / kTileRows, 4);
@@ -1137,6 +1140,18 @@ static int vec_copy(eigenex_basis_t b, int ref, double* host, bool up) {
 
 int eigenex_vec_upload(eigenex_basis_t b, int ref, const double* host) { return vec_copy(b, ref, const_cast<double*>(host), true); }
 int eigenex_vec_download(eigenex_basis_t b, int ref, double* host) { return vec_copy(b, ref, host, false); }
+
+int eigenex_vec_copy(eigenex_basis_t b, int dst_ref, int src_ref) {
+  if (!b) return fail(EIGENEX_ERR_ARG, "basis is NULL");
+  eigenex_context_s* c = b->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  for (auto& s : b->sh) {
+    double *d = vec_ptr(s, b->cap, b->nq, dst_ref), *x = vec_ptr(s, b->cap, b->nq, src_ref);
+    if (!d || !x) return fail(EIGENEX_ERR_ARG, "bad vector reference");
+    if (d != x) HIPCHK(hipMemcpyAsync(d, x, sizeof(double) * s.nloc, hipMemcpyDeviceToDevice, c->stream));
+  }
+  return 0;
+}
 
 // ---- step primitives -------------------------------------------------------------
 static int fetch_h(eigenex_basis_t b, int off, int n, double* host) {

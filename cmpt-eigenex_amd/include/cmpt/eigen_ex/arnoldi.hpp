@@ -108,10 +108,12 @@ class ArnoldiBase {
   const VectorType& initialVector() const { return initialVector_; }
   ArnoldiBase& setInitialVector(const VectorType& inivec) {
     initialVector_ = inivec;
+    initialDirty_ = true;
     return *this;
   }
   ArnoldiBase& setInitialVector(VectorType&& inivec) {
     initialVector_ = std::move(inivec);
+    initialDirty_ = true;
     return *this;
   }
   ArnoldiBase& setInitialVector() {
@@ -260,6 +262,7 @@ class ArnoldiBase {
       devNq_ = nq;
       devOp_ = deviceOperator_.get();
       orthoDirty_ = true;
+      devCreated_ = true;
     } else if (dev_.capacity() < vectorsNeeded) {
       dev_.reserve(static_cast<int>(std::max<Index>(vectorsNeeded, 2 * dev_.capacity())));
     }
@@ -279,7 +282,10 @@ class ArnoldiBase {
     ensureDevice_(std::min<Index>(callsEnqueued_ + ncalls, matrixHeight_));
     if (!started_) {
       setInitialArnoldivector();
-      dev_.upload(EIGENEX_VEC_W, initialVector_);
+      // the start vector crosses PCIe only when it has changed; every solve begins with a device copy
+      if (initialDirty_ || devCreated_) dev_.upload(EIGENEX_VEC_START, initialVector_);
+      initialDirty_ = devCreated_ = false;
+      device::check(eigenex_vec_copy(dev_.handle(), EIGENEX_VEC_W, EIGENEX_VEC_START), "eigenex_vec_copy");
       started_ = true;
     }
     device::check(eigenex_arnoldi_enqueue(dev_.handle(), static_cast<int>(ncalls)), "eigenex_arnoldi_enqueue");
@@ -334,6 +340,8 @@ class ArnoldiBase {
   int devNq_ = -1;
   const device::CsrOperator* devOp_ = nullptr;
   bool orthoDirty_ = true;
+  bool initialDirty_ = true;
+  bool devCreated_ = false;
   bool started_ = false;
   Index callsEnqueued_ = 0, callsRevealed_ = 0, devCallsTrue_ = 0;
   std::vector<double> devH_;

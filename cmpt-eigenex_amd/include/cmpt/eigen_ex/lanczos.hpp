@@ -227,10 +227,12 @@ class LanczosBase {
   const VectorType& initialVector() const { return initialVector_; }
   LanczosBase& setInitialVector(const VectorType& inivec) {
     initialVector_ = inivec;
+    initialDirty_ = true;
     return *this;
   }
   LanczosBase& setInitialVector(VectorType&& inivec) {
     initialVector_ = std::move(inivec);
+    initialDirty_ = true;
     return *this;
   }
   // random contents from a default-seeded std::mt19937 (reference :214-218)
@@ -366,6 +368,7 @@ class LanczosBase {
       devNq_ = nq;
       devOp_ = deviceOperator_.get();
       orthoDirty_ = true;
+      devCreated_ = true;
     } else if (dev_.capacity() < vectorsNeeded) {
       dev_.reserve(static_cast<int>(std::max<Index>(vectorsNeeded, 2 * dev_.capacity())));
     }
@@ -387,7 +390,10 @@ class LanczosBase {
     ensureDevice_(callsEnqueued_ + ncalls);
     if (!started_) {
       setInitialLanczosvector();
-      dev_.upload(EIGENEX_VEC_W, initialVector_);
+      // the start vector crosses PCIe only when it has changed; every solve begins with a device copy
+      if (initialDirty_ || devCreated_) dev_.upload(EIGENEX_VEC_START, initialVector_);
+      initialDirty_ = devCreated_ = false;
+      device::check(eigenex_vec_copy(dev_.handle(), EIGENEX_VEC_W, EIGENEX_VEC_START), "eigenex_vec_copy");
       started_ = true;
     }
     device::check(eigenex_lanczos_enqueue(dev_.handle(), static_cast<int>(ncalls)), "eigenex_lanczos_enqueue");
@@ -446,6 +452,8 @@ class LanczosBase {
   int devNq_ = -1;
   const device::CsrOperator* devOp_ = nullptr;
   bool orthoDirty_ = true;
+  bool initialDirty_ = true;
+  bool devCreated_ = false;
   bool started_ = false;
   Index callsEnqueued_ = 0, callsRevealed_ = 0, devCallsTrue_ = 0;
   std::vector<double> devAlpha_, devBeta_;

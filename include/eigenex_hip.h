@@ -64,6 +64,7 @@ enum {
 #define EIGENEX_VEC_COL(c) ((int)(c))        /* basis vector c (lanczosvectors_[c] / arnoldivectors_[c]) */
 #define EIGENEX_VEC_V (-1)                    /* v_: holds A*u (lanczos.hpp:237, arnoldi.hpp:185) */
 #define EIGENEX_VEC_W (-2)                    /* work vector that feeds the operator (with halo space) */
+#define EIGENEX_VEC_START (-3)                /* device-resident copy of initialVector_ (lanczos.hpp:158); survives clear */
 #define EIGENEX_VEC_ORTHO(q) (-16 - (int)(q)) /* orthogonalizingVectors_[q] (lanczos.hpp:153) */
 
 /* operator callback for operators that live in host code: the reference's
@@ -142,6 +143,8 @@ int eigenex_basis_clear(eigenex_basis_t b);
 /* host <-> device vectors (rows owned by this context) */
 int eigenex_vec_upload(eigenex_basis_t b, int vec_ref, const double* host);
 int eigenex_vec_download(eigenex_basis_t b, int vec_ref, double* host);
+/* device-to-device copy dst = src (e.g. W = START before the first step: no PCIe traffic per solve) */
+int eigenex_vec_copy(eigenex_basis_t b, int dst_ref, int src_ref);
 
 /* ---- step primitives (each one parity-tested on its own; all synchronise) -- */
 /* y = A*x + shift*x ; if dot != NULL also *dot = x . y      (a1, a2, a3 of SURVEY 8a) */
