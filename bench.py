@@ -104,10 +104,9 @@ def main():
     N = n ** 3
     ctx = capi.Context(device=local_rank, rank=rank, world_size=world, rccl_id=rccl_id)
     A = capi.Csr.laplacian3d(ctx, n)
-    rb, re = capi.partition(N, world, rank)
-    # same global start vector on every rank (seeded N(0,1)); each rank passes its rows
-    init = np.random.default_rng(20240601).standard_normal(N)[rb:re].copy() if world > 1 else \
-        np.random.default_rng(20240601).standard_normal(N)
+    # same global start vector on every rank (seeded N(0,1)), as in the reference API where
+    # initialVector has matrixHeight entries; each rank uploads its own rows once, before the timed region
+    init = np.random.default_rng(20240601).standard_normal(N)
 
     es = solver.LanczosEigenSolver()
     es.setDeviceOperator(A).set(minIterations=m, maxIterations=m, computeEigenvectorsOn=0, initialVector=init,

@@ -1,0 +1,147 @@
+"""CPU tests: the C-ABI library loads without a GPU and exports every symbol the public header
+declares; host-only logic (row partition, halo plan, small dense eigen-solvers, default start
+vector) is checked against numpy/LAPACK and the oracle.  No compute call touches a GPU here.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import cref
+from oracle.stl_random import libstdcxx_normal_vector
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+
+    g.build()
+    from cmpt_eigenex_amd import capi, solver
+
+    return capi, solver
+
+
+def _declared_functions(header_path):
+    text = open(header_path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(eigenex_[a-z0-9_]+)\s*\(", text)) - {"eigenex_matvec_fn"})
+
+
+def test_library_exports_every_declared_symbol(built):
+    capi, _ = built
+    names = _declared_functions(os.path.join(ROOT, "include", "eigenex_hip.h"))
+    assert len(names) >= 35
+    L = capi.lib()
+    for n in names:
+        assert hasattr(L, n), f"{n} is declared in include/eigenex_hip.h but not exported"
+        assert n in capi.SIGNATURES, f"{n} has no ctypes signature in capi.py"
+    assert sorted(capi.SIGNATURES) == names
+    assert L.eigenex_version() == 100
+
+
+def test_fails_loudly_without_gpu(built):
+    capi, solver = built
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(capi.EigenexError, match="no HIP device|no CPU path|NODEVICE|hipGetDeviceCount"):
+        capi.Context()
+    # the solver classes have no host fallback either: the first step needs the device
+    es = solver.LanczosEigenSolver()
+    es.setMatrixMultiplication(lambda x: x, 4)
+    with pytest.raises(capi.EigenexError):
+        es.compute()
+
+
+def test_argument_errors_are_reported(built):
+    capi, _ = built
+    L = capi.lib()
+    b, e = C.c_int64(), C.c_int64()
+    assert L.eigenex_partition(10, 0, 0, C.byref(b), C.byref(e)) == -1
+    assert b"bad argument" in L.eigenex_last_error()
+    assert L.eigenex_context_destroy(None) == 0
+    assert L.eigenex_csr_destroy(None) == 0
+    assert L.eigenex_basis_destroy(None) == 0
+
+
+@pytest.mark.parametrize("n,P", [(10, 3), (7, 7), (1 << 27, 8), (1000003, 6), (5, 8)])
+def test_partition_is_a_contiguous_cover(built, n, P):
+    capi, _ = built
+    edges = [capi.partition(n, P, s) for s in range(P)]
+    assert edges[0][0] == 0 and edges[-1][1] == n
+    for (b0, e0), (b1, e1) in zip(edges, edges[1:]):
+        assert e0 == b1 and b0 <= e0
+    sizes = [e - b for b, e in edges]
+    assert max(sizes) - min(sizes) <= 1
+
+
+def test_halo_plan_matches_numpy(built):
+    capi, _ = built
+    n = 12
+    N = n ** 3
+    P = 5
+    for s in range(P):
+        rb, re = capi.partition(N, P, s)
+        rowptr, col, val = cref.laplacian3d(n, rb, re)
+        cols, per_owner = capi.halo_plan(N, P, s, col)
+        remote = np.unique(col[(col < rb) | (col >= re)])
+        np.testing.assert_array_equal(cols, remote)
+        owners = np.array([next(o for o in range(P) if capi.partition(N, P, o)[0] <= c < capi.partition(N, P, o)[1]) for c in remote], int)
+        np.testing.assert_array_equal(per_owner, np.bincount(owners, minlength=P))
+        assert per_owner[s] == 0
+    # a 7-point stencil only talks to row-neighbours
+    rb, re = capi.partition(N, P, 2)
+    _, col, _ = cref.laplacian3d(n, rb, re)
+    _, per_owner = capi.halo_plan(N, P, 2, col)
+    assert per_owner[0] == 0 and per_owner[4] == 0 and per_owner[1] > 0 and per_owner[3] > 0
+
+
+def test_small_eigen_tridiagonal_vs_lapack(built):
+    _, solver = built
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 3, 17, 101, 257):
+        a = rng.standard_normal(n)
+        b = rng.standard_normal(max(n - 1, 0))
+        vals, vecs = solver.tridiagonal_eigen(a, b)
+        T = np.diag(a) + np.diag(b, 1) + np.diag(b, -1)
+        np.testing.assert_allclose(vals, np.linalg.eigvalsh(T), atol=1e-12)
+        assert np.abs(T @ vecs - vecs * vals).max() < 1e-12
+        assert np.abs(vecs.T @ vecs - np.eye(n)).max() < 1e-12
+        vals2, _ = solver.tridiagonal_eigen(a, b, vectors=False)
+        np.testing.assert_allclose(vals2, vals, atol=1e-13)
+    # degenerate cases: zero sub-diagonal, repeated eigenvalues, surplus beta entry is ignored
+    vals, vecs = solver.tridiagonal_eigen([2.0, 2.0, 1.0], [0.0, 0.0])
+    np.testing.assert_allclose(vals, [1.0, 2.0, 2.0])
+    vals, _ = solver.tridiagonal_eigen([1.5, 1.5], [1e-15, 123.0][:1])
+    np.testing.assert_allclose(vals, [1.5, 1.5], atol=1e-14)
+
+
+def test_small_eigen_hessenberg_vs_lapack(built):
+    _, solver = built
+    rng = np.random.default_rng(1)
+    for n in (1, 2, 5, 33, 80):
+        for real in (True, False):
+            H = rng.standard_normal((n, n)) + (0 if real else 1j * rng.standard_normal((n, n)))
+            H = np.triu(H, -1)
+            vals, vecs = solver.hessenberg_eigen(H)
+            ref = list(np.linalg.eigvals(H))
+            for v in vals:
+                k = int(np.argmin([abs(v - r) for r in ref]))
+                assert abs(v - ref.pop(k)) < 1e-10
+            assert np.abs(H @ vecs - vecs * vals).max() < 1e-10
+            np.testing.assert_allclose(np.linalg.norm(vecs, axis=0), 1.0, atol=1e-12)
+
+
+def test_default_start_vector_is_the_references(built):
+    """lanczos.hpp:214-218: std::mt19937 default seed + std::normal_distribution, normalised."""
+    _, solver = built
+    v = solver.default_start_vector(5000)
+    r = libstdcxx_normal_vector(5000)
+    r /= np.linalg.norm(r)
+    np.testing.assert_allclose(v, r, rtol=0, atol=1e-16)
+    w = solver.random_vector(1, 64)
+    r1 = libstdcxx_normal_vector(64, seed=1)
+    np.testing.assert_allclose(w, r1 / np.linalg.norm(r1), rtol=0, atol=1e-16)
