@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 CSV output (gpurun_out/prof_*) into the summaries committed under profiles/.
+
+  python scripts/summarize_rocprof.py ROUND WORKLOAD_KEY STATS_DIR FETCH_DIR WRITE_DIR
+
+Writes profiles/rNN_kernel_stats.csv (verbatim rocprofv3 --kernel-trace --stats summary),
+profiles/rNN_summary.md and profiles/hbm_traffic.json (read by bench.py for roofline.traffic).
+
+HBM bytes per launch follow /opt/skills/guides/MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE
+are collected in separate --pmc passes (they do not fit one pass), are in KiB, and on gfx950
+FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read, so
+bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name: str) -> str:
+    name = name.split("(")[0] if not name.startswith("eigenex::(") else name[len("eigenex::(anonymous namespace)::"):].split("(")[0]
+    return name.strip()
+
+
+def load_counter(d: str, counter: str):
+    per = defaultdict(list)
+    for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] == counter:
+                per[short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
+    return per
+
+
+def main():
+    rnd, key, stats_dir, fetch_dir, write_dir = sys.argv[1:6]
+    out_dir = os.path.join(ROOT, "profiles")
+    os.makedirs(out_dir, exist_ok=True)
+    stats_file = glob.glob(os.path.join(stats_dir, "**", "*_kernel_stats.csv"), recursive=True)[0]
+    shutil.copy(stats_file, os.path.join(out_dir, f"{rnd}_kernel_stats.csv"))
+    stats = {short(r["Name"]): r for r in csv.DictReader(open(stats_file))}
+    fetch = load_counter(fetch_dir, "FETCH_SIZE")
+    write = load_counter(write_dir, "WRITE_SIZE")
+    traffic = {}
+    lines = [f"# rocprofv3 summary, round {rnd}: {key}", "",
+             "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline`",
+             "PMC: separate passes `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` over `bench.py --steps 1 --warmup 0`; "
+             "HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 correction of MI355X_MICROARCH.md).", "",
+             "| kernel | calls | avg ms | % time | HBM bytes/launch (PMC) | fetch KiB avg (raw) | write KiB avg |", "|---|---|---|---|---|---|---|"]
+    for k, r in sorted(stats.items(), key=lambda kv: -float(kv[1]["TotalDurationNs"])):
+        f = fetch.get(k, [])
+        w = write.get(k, [])
+        bpl = None
+        if f and w:
+            bpl = (2.0 * sum(f) / len(f) + sum(w) / len(w)) * 1024.0
+            traffic[k] = {"bytes_per_launch": bpl, "fetch_kib_avg_raw": sum(f) / len(f), "write_kib_avg": sum(w) / len(w),
+                          "launches_profiled": len(f)}
+        lines.append(f"| {k} | {r['Calls']} | {float(r['AverageNs'])/1e6:.4f} | {r['Percentage']} | "
+                     f"{bpl:.4g} |" f" {sum(f)/len(f):.4g} | {sum(w)/len(w):.4g} |" if bpl else
+                     f"| {k} | {r['Calls']} | {float(r['AverageNs'])/1e6:.4f} | {r['Percentage']} | - | - | - |")
+    open(os.path.join(out_dir, f"{rnd}_summary.md"), "w").write("\n".join(lines) + "\n")
+    tfile = os.path.join(out_dir, "hbm_traffic.json")
+    allt = json.load(open(tfile)) if os.path.exists(tfile) else {}
+    allt[key] = traffic
+    json.dump(allt, open(tfile, "w"), indent=1, sort_keys=True)
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
