@@ -103,6 +103,8 @@ def main():
     n, m = args.n, args.m
     N = n ** 3
     ctx = capi.Context(device=local_rank, rank=rank, world_size=world, rccl_id=rccl_id)
+    if world > 1 and not ctx.rccl_selftest():
+        sys.exit(f"rank {rank}: RCCL self-test (all-reduce / all-gather / send-recv ring) returned wrong data")
     A = capi.Csr.laplacian3d(ctx, n)
     # same global start vector on every rank (seeded N(0,1)), as in the reference API where
     # initialVector has matrixHeight entries; each rank uploads its own rows once, before the timed region

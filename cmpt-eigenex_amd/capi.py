@@ -58,6 +58,7 @@ SIGNATURES = {
     "eigenex_context_create": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
     "eigenex_context_create_loopback": (C.c_int, [C.c_int, C.c_int, C.POINTER(_vp)]),
     "eigenex_context_destroy": (C.c_int, [_vp]),
+    "eigenex_context_selftest": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "eigenex_context_sync": (C.c_int, [_vp]),
     "eigenex_context_info": (C.c_int, [_vp] + [C.POINTER(C.c_int)] * 4),
     "eigenex_context_stream": (_vp, [_vp]),
@@ -169,6 +170,11 @@ class Context:
 
     def sync(self):
         _chk(lib().eigenex_context_sync(self.h))
+
+    def rccl_selftest(self) -> bool:
+        ok = C.c_int(0)
+        _chk(lib().eigenex_context_selftest(self.h, C.byref(ok)))
+        return bool(ok.value)
 
     def profile_enable(self, on=True):
         _chk(lib().eigenex_profile_enable(self.h, 1 if on else 0))

@@ -210,7 +210,7 @@ namespace {
 // in-place sum over all shards of hbuf[off .. off+n) on every shard
 int allreduce(eigenex_basis_s* b, int off, int n) {
   eigenex_context_s* c = b->ctx;
-  if (c->P == 1 || n <= 0) return 0;
+  if ((c->P == 1 && !c->comm) || n <= 0) return 0;  // a 1-rank communicator (self-test) still goes through RCCL
   ProfScope ps(c, EIGENEX_K_COMM, 0.0);
   if (c->loopback) {
     PtrPack pk;
@@ -740,7 +740,7 @@ int eigenex_context_create(int device, int rank, int world_size, const void* rcc
   c->world = world_size;
   c->P = world_size;
   c->local = {rank};
-  if (world_size > 1) {
+  if (rccl_id128) {  // also at world_size 1 when an id is given: a 1-rank communicator for the RCCL self-test
     ncclUniqueId id;
     std::memcpy(&id, rccl_id128, sizeof(id));
     ncclResult_t r = ncclCommInitRank(&c->comm, world_size, id, rank);
@@ -752,6 +752,47 @@ int eigenex_context_create(int device, int rank, int world_size, const void* rcc
     }
   }
   *out = c;
+  return 0;
+}
+
+// Exercises every RCCL call the data path uses, on the context's communicator and stream:
+// all-reduce (fp64 sum, in place), all-gather, and a grouped send/recv ring (rank -> rank+1;
+// at world_size 1 a send to self).  *ok = 1 when every received value is the expected one.
+int eigenex_context_selftest(eigenex_context_t c, int* ok) {
+  if (!c || !ok) return fail(EIGENEX_ERR_ARG, "NULL argument");
+  *ok = 0;
+  if (!c->comm) return fail(EIGENEX_ERR_STATE, "context has no RCCL communicator");
+  HIPCHK(hipSetDevice(c->device));
+  const int W = c->world, n = 1000;
+  double* d = nullptr;
+  HIPCHK(hipMalloc(&d, sizeof(double) * (size_t)(3 * n + n * W)));
+  double *a = d, *snd = d + n, *rcv = d + 2 * n, *gat = d + 3 * n;
+  std::vector<double> h((size_t)n);
+  for (int i = 0; i < n; ++i) h[i] = (double)(c->rank + 1) * 1000.0 + i;
+  HIPCHK(hipMemcpyAsync(a, h.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(snd, h.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemsetAsync(rcv, 0, sizeof(double) * n, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  NCCLCHK(ncclAllReduce(a, a, (size_t)n, ncclDouble, ncclSum, c->comm, c->stream));
+  NCCLCHK(ncclAllGather(snd, gat, (size_t)n, ncclDouble, c->comm, c->stream));
+  NCCLCHK(ncclGroupStart());
+  NCCLCHK(ncclSend(snd, (size_t)n, ncclDouble, (c->rank + 1) % W, c->comm, c->stream));
+  NCCLCHK(ncclRecv(rcv, (size_t)n, ncclDouble, (c->rank + W - 1) % W, c->comm, c->stream));
+  NCCLCHK(ncclGroupEnd());
+  std::vector<double> ha((size_t)n), hr((size_t)n), hg((size_t)n * W);
+  HIPCHK(hipMemcpyAsync(ha.data(), a, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(hr.data(), rcv, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(hg.data(), gat, sizeof(double) * n * W, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  (void)hipFree(d);
+  bool good = true;
+  const int prev = (c->rank + W - 1) % W;
+  for (int i = 0; i < n && good; ++i) {
+    const double sum = 1000.0 * W * (W + 1) / 2.0 + (double)W * i;
+    good = ha[i] == sum && hr[i] == (double)(prev + 1) * 1000.0 + i;
+    for (int r = 0; r < W && good; ++r) good = hg[(size_t)r * n + i] == (double)(r + 1) * 1000.0 + i;
+  }
+  *ok = good ? 1 : 0;
   return 0;
 }
 

@@ -96,6 +96,10 @@ int eigenex_context_create(int device, int rank, int world_size, const void* rcc
 /* all `nshards` shards in this process on `device` (verification transport) */
 int eigenex_context_create_loopback(int device, int nshards, eigenex_context_t* out);
 int eigenex_context_destroy(eigenex_context_t ctx);
+/* runs every RCCL call of the data path once on this context's communicator and stream (all-reduce,
+ * all-gather, grouped send/recv ring) and checks the received values; collective. A context created
+ * with world_size 1 AND a non-NULL rccl_id owns a 1-rank communicator for this purpose. */
+int eigenex_context_selftest(eigenex_context_t ctx, int* ok);
 int eigenex_context_sync(eigenex_context_t ctx);
 int eigenex_context_info(eigenex_context_t ctx, int* rank, int* world_size, int* nshards_total, int* nshards_local);
 /* the context's hipStream_t (as void*) */
