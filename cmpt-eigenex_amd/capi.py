@@ -66,10 +66,14 @@ SIGNATURES = {
     "eigenex_profile_reset": (C.c_int, [_vp]),
     "eigenex_profile_get": (C.c_int, [_vp, C.c_int, _lp, _dp, _dp]),
     "eigenex_csr_upload": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int64, _ip, _ip, _dp, C.POINTER(_vp)]),
+    "eigenex_csr_upload_z": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int64, _ip, _ip, _dp, C.POINTER(_vp)]),
     "eigenex_csr_laplacian3d": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp)]),
     "eigenex_csr_destroy": (C.c_int, [_vp]),
     "eigenex_csr_info": (C.c_int, [_vp, _lp, _lp, _lp, _lp]),
     "eigenex_basis_create": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "eigenex_basis_create_ex": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "eigenex_basis_is_complex": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "eigenex_basis_configure_z": (C.c_int, [_vp, C.c_double, C.c_double, C.c_double, C.c_int64, C.c_int]),
     "eigenex_basis_destroy": (C.c_int, [_vp]),
     "eigenex_basis_set_host_operator": (C.c_int, [_vp, MATVEC_FN, _vp]),
     "eigenex_basis_configure": (C.c_int, [_vp, C.c_double, C.c_double, C.c_int64, C.c_int]),
@@ -205,12 +209,19 @@ class Csr:
 
     @classmethod
     def upload(cls, ctx: Context, n_global: int, rowptr, col, val, row_begin: int = 0):
+        """val real (float64) or complex (complex128: uploaded as interleaved pairs, eigenex_csr_upload_z)."""
         rp = np.ascontiguousarray(rowptr, np.int32)
         cl = np.ascontiguousarray(col, np.int32)
-        vl = np.ascontiguousarray(val, np.float64)
         h = _vp()
-        _chk(lib().eigenex_csr_upload(ctx.h, n_global, row_begin, rp.size - 1, _i(rp), _i(cl), _d(vl), C.byref(h)))
-        return cls(ctx, h)
+        if np.iscomplexobj(val):
+            vl = np.ascontiguousarray(val, np.complex128)
+            _chk(lib().eigenex_csr_upload_z(ctx.h, n_global, row_begin, rp.size - 1, _i(rp), _i(cl), _d(vl.view(np.float64)), C.byref(h)))
+        else:
+            vl = np.ascontiguousarray(val, np.float64)
+            _chk(lib().eigenex_csr_upload(ctx.h, n_global, row_begin, rp.size - 1, _i(rp), _i(cl), _d(vl), C.byref(h)))
+        obj = cls(ctx, h)
+        obj.is_complex = bool(np.iscomplexobj(val))
+        return obj
 
     @classmethod
     def laplacian3d(cls, ctx: Context, n: int):
@@ -236,12 +247,18 @@ class Csr:
 
 
 class Basis:
-    """Krylov state on the device (basis slab, work vectors, coefficient arrays)."""
+    """Krylov state on the device (basis slab, work vectors, coefficient arrays).
+    dtype float64 or complex128 (taken from the CSR operator when one is given)."""
 
-    def __init__(self, ctx: Context, csr: Csr | None, n_global: int, capacity: int, n_ortho: int = 0):
+    def __init__(self, ctx: Context, csr: Csr | None, n_global: int, capacity: int, n_ortho: int = 0, dtype=None):
         self.ctx, self.csr, self.n_global, self.capacity, self.n_ortho = ctx, csr, n_global, capacity, n_ortho
+        if dtype is None:
+            dtype = np.complex128 if (csr is not None and getattr(csr, "is_complex", False)) else np.float64
+        self.dtype = np.dtype(dtype)
+        self.is_complex = self.dtype.kind == "c"
         self.h = _vp()
-        _chk(lib().eigenex_basis_create(ctx.h, csr.h if csr else None, n_global, capacity, n_ortho, C.byref(self.h)))
+        _chk(lib().eigenex_basis_create_ex(ctx.h, csr.h if csr else None, n_global, capacity, n_ortho,
+                                           1 if self.is_complex else 0, C.byref(self.h)))
         info = ctx.info()
         if info["nshards_local"] == info["nshards_total"]:
             self.n_rows = n_global
@@ -250,16 +267,21 @@ class Basis:
             self.n_rows = e - b
         self._cb = None
 
+    def _vec(self, x):
+        x = np.ascontiguousarray(x, self.dtype)
+        return x, _d(x.view(np.float64))
+
     def configure(self, shift=0.0, threshold=1e-12, interval=1, ortho_mode=ORTHO_BATCHED):
-        _chk(lib().eigenex_basis_configure(self.h, shift, threshold, interval, ortho_mode))
+        sh = complex(shift)
+        _chk(lib().eigenex_basis_configure_z(self.h, sh.real, sh.imag, threshold, interval, ortho_mode))
 
     def set_host_operator(self, fn):
         """fn(x: ndarray) -> ndarray  (the reference's MatMulFunction, lanczos.hpp:116)."""
-        n = self.n_rows
+        n, es, dt = self.n_rows, (2 if self.is_complex else 1), self.dtype
 
         def tramp(pin, pout, _user):
-            x = np.ctypeslib.as_array(pin, shape=(n,))
-            y = np.ctypeslib.as_array(pout, shape=(n,))
+            x = np.ctypeslib.as_array(pin, shape=(n * es,)).view(dt)
+            y = np.ctypeslib.as_array(pout, shape=(n * es,)).view(dt)
             y[:] = fn(x)
 
         self._cb = MATVEC_FN(tramp)
@@ -269,9 +291,9 @@ class Basis:
         _chk(lib().eigenex_basis_clear(self.h))
 
     def upload(self, ref: int, x):
-        x = np.ascontiguousarray(x, np.float64)
+        x, p = self._vec(x)
         assert x.size == self.n_rows
-        _chk(lib().eigenex_vec_upload(self.h, ref, _d(x)))
+        _chk(lib().eigenex_vec_upload(self.h, ref, p))
 
     def copy(self, dst_ref: int, src_ref: int):
         _chk(lib().eigenex_vec_copy(self.h, dst_ref, src_ref))
@@ -281,26 +303,25 @@ class Basis:
         self.capacity = max(self.capacity, capacity)
 
     def download(self, ref: int):
-        x = np.empty(self.n_rows, np.float64)
-        _chk(lib().eigenex_vec_download(self.h, ref, _d(x)))
+        x = np.empty(self.n_rows, self.dtype)
+        _chk(lib().eigenex_vec_download(self.h, ref, _d(x.view(np.float64))))
         return x
 
     # -- primitives
     def apply(self, x_ref, y_ref, shift=0.0, want_dot=False):
-        d = C.c_double()
-        _chk(lib().eigenex_apply(self.h, x_ref, y_ref, shift, C.byref(d) if want_dot else None))
-        return d.value if want_dot else None
+        d = np.zeros(1, self.dtype)
+        _chk(lib().eigenex_apply(self.h, x_ref, y_ref, shift, _d(d.view(np.float64)) if want_dot else None))
+        return d[0] if want_dot else None
 
     def dots(self, w_ref, first, stride, count, n_ortho_used=0):
-        h = np.zeros(count + n_ortho_used)
-        _chk(lib().eigenex_dots(self.h, w_ref, first, stride, count, n_ortho_used, _d(h)))
+        h = np.zeros(count + n_ortho_used, self.dtype)
+        _chk(lib().eigenex_dots(self.h, w_ref, first, stride, count, n_ortho_used, _d(h.view(np.float64))))
         return h
 
     def update(self, w_ref, first, stride, count, h, n_ortho_used=0):
-        h = np.ascontiguousarray(h, np.float64)
+        h, p = self._vec(h)
         nrm2 = C.c_double()
-        _chk(lib().eigenex_update(self.h, w_ref, first, stride, count, n_ortho_used, _d(h) if h.size else None,
-                                  C.byref(nrm2)))
+        _chk(lib().eigenex_update(self.h, w_ref, first, stride, count, n_ortho_used, p if h.size else None, C.byref(nrm2)))
         return nrm2.value
 
     def axpy2(self, z_ref, x_ref, a, p_ref, b, q_ref):
@@ -326,17 +347,26 @@ class Basis:
     def arnoldi_state(self):
         st = State()
         ldh = self.capacity + 2
-        H = np.zeros((self.capacity + 1, ldh))  # row c = column c of H
-        _chk(lib().eigenex_arnoldi_state(self.h, C.byref(st), _d(H), ldh))
+        H = np.zeros((self.capacity + 1, ldh), self.dtype)  # row c = column c of H
+        _chk(lib().eigenex_arnoldi_state(self.h, C.byref(st), _d(H.view(np.float64)), ldh))
         m = min(st.nalpha, self.n_global)
         return st, H[:m, :m].T.copy()
 
     def ritz_vectors(self, nvec: int, S):
-        S = np.asfortranarray(S, np.float64)
+        """X = V S, normalised and phase-fixed.  Real S: X has the basis dtype; complex S: X is complex."""
         nev = S.shape[1]
-        X = np.zeros((self.n_rows, nev), order="F")
+        if np.iscomplexobj(S):
+            S = np.asfortranarray(S, np.complex128)
+            Sr, Si = np.asfortranarray(S.real), np.asfortranarray(S.imag)
+            X = np.zeros((self.n_rows, nev), np.complex128, order="F")
+            if nev:
+                _chk(lib().eigenex_ritz_vectors_complex(self.h, nvec, nev, _d(Sr), _d(Si), S.shape[0],
+                                                        X.ctypes.data_as(_dp), self.n_rows))
+            return X
+        S = np.asfortranarray(S, np.float64)
+        X = np.zeros((self.n_rows, nev), self.dtype, order="F")
         if nev:
-            _chk(lib().eigenex_ritz_vectors(self.h, nvec, nev, _d(S), S.shape[0], _d(X), self.n_rows))
+            _chk(lib().eigenex_ritz_vectors(self.h, nvec, nev, _d(S), S.shape[0], X.ctypes.data_as(_dp), self.n_rows))
         return X
 
     def close(self):

@@ -80,23 +80,32 @@ __device__ __forceinline__ void load_col(double2 (&x)[4], const double* __restri
   }
 }
 
-__device__ __forceinline__ double dot8(const double2 (&w)[4], const double2 (&x)[4]) {
-  double s = 0.0;
+// ---------------------------------------------------------------------------
+// dots: partial h_c = sum_rows conj(col_c[row]) * w0[row] for every selected column.
+// One pass over the selected part of the slab; 16 x 16-B loads in flight per lane.
+// All lengths are in doubles: a complex vector of N entries is 2N interleaved doubles
+// and one double2 load is one complex entry (CPLX) or two real rows.  The three-term
+// recurrence has real coefficients (lanczos.hpp:403-408), so w0 is formed the same way.
+// ---------------------------------------------------------------------------
+template <bool CPLX>
+__device__ __forceinline__ void dotc8(const double2 (&w)[4], const double2 (&x)[4], double& sr, double& si) {
+  sr = 0.0;
+  si = 0.0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    s = fma(w[i].x, x[i].x, s);
-    s = fma(w[i].y, x[i].y, s);
+    sr = fma(x[i].x, w[i].x, sr);
+    sr = fma(x[i].y, w[i].y, sr);
+    if (CPLX) {  // conj(x) * w, imaginary part
+      si = fma(x[i].x, w[i].y, si);
+      si = fma(-x[i].y, w[i].x, si);
+    }
   }
-  return s;
 }
 
-// ---------------------------------------------------------------------------
-// dots: partial h_c = sum_rows col_c[row] * w0[row] for every selected column.
-// One pass over the selected part of the slab; 16 x 16-B loads in flight per lane.
-// ---------------------------------------------------------------------------
-template <bool FULL>
+template <bool FULL, bool CPLX>
 __device__ __forceinline__ void dots_tile(const double* __restrict__ src, const ThreeTerm& tt, double a, double b,
                                           const ColumnSet& cs, int ncols, int64_t base, int64_t n, double* wave_acc) {
+  constexpr int ES = CPLX ? 2 : 1;
   const int lane = threadIdx.x & 63;
   double2 w[4];
   load_w0<FULL>(w, src, tt, a, b, base, n);
@@ -107,63 +116,100 @@ __device__ __forceinline__ void dots_tile(const double* __restrict__ src, const 
     load_col<FULL>(x1, column_ptr(cs, ci + 1), base, n);
     load_col<FULL>(x2, column_ptr(cs, ci + 2), base, n);
     load_col<FULL>(x3, column_ptr(cs, ci + 3), base, n);
-    double s0 = dot8(w, x0), s1 = dot8(w, x1), s2 = dot8(w, x2), s3 = dot8(w, x3);
-    s0 = wave_sum(s0);
-    s1 = wave_sum(s1);
-    s2 = wave_sum(s2);
-    s3 = wave_sum(s3);
+    double r0, r1, r2, r3, i0, i1, i2, i3;
+    dotc8<CPLX>(w, x0, r0, i0);
+    dotc8<CPLX>(w, x1, r1, i1);
+    dotc8<CPLX>(w, x2, r2, i2);
+    dotc8<CPLX>(w, x3, r3, i3);
+    r0 = wave_sum(r0);
+    r1 = wave_sum(r1);
+    r2 = wave_sum(r2);
+    r3 = wave_sum(r3);
+    if (CPLX) {
+      i0 = wave_sum(i0);
+      i1 = wave_sum(i1);
+      i2 = wave_sum(i2);
+      i3 = wave_sum(i3);
+    }
     if (lane == 0) {
-      wave_acc[ci + 0] += s0;
-      wave_acc[ci + 1] += s1;
-      wave_acc[ci + 2] += s2;
-      wave_acc[ci + 3] += s3;
+      wave_acc[ES * (ci + 0)] += r0;
+      wave_acc[ES * (ci + 1)] += r1;
+      wave_acc[ES * (ci + 2)] += r2;
+      wave_acc[ES * (ci + 3)] += r3;
+      if (CPLX) {
+        wave_acc[ES * (ci + 0) + 1] += i0;
+        wave_acc[ES * (ci + 1) + 1] += i1;
+        wave_acc[ES * (ci + 2) + 1] += i2;
+        wave_acc[ES * (ci + 3) + 1] += i3;
+      }
     }
   }
   for (; ci < ncols; ++ci) {
     double2 x0[4];
     load_col<FULL>(x0, column_ptr(cs, ci), base, n);
-    double s0 = wave_sum(dot8(w, x0));
-    if (lane == 0) wave_acc[ci] += s0;
+    double r0, i0;
+    dotc8<CPLX>(w, x0, r0, i0);
+    r0 = wave_sum(r0);
+    if (CPLX) i0 = wave_sum(i0);
+    if (lane == 0) {
+      wave_acc[ES * ci] += r0;
+      if (CPLX) wave_acc[ES * ci + 1] += i0;
+    }
   }
 }
 
+// partials[(ES*c + part)*pstride + block]
+template <bool CPLX>
 __global__ __launch_bounds__(kBlock) void k_dots(const double* __restrict__ src, ThreeTerm tt, ColumnSet cs,
                                                  int64_t n, int64_t ntiles, double* __restrict__ partials,
                                                  int pstride, const Ctrl* __restrict__ ctrl) {
-  extern __shared__ double lds[];  // [4 waves][ncols]
+  extern __shared__ double lds[];  // [4 waves][ES*ncols]
   if (ctrl->stopped) return;
+  constexpr int ES = CPLX ? 2 : 1;
   const int ncols = cs.count + cs.nq;
+  const int nacc = ES * ncols;
   const int wave = threadIdx.x >> 6;
-  for (int i = threadIdx.x; i < 4 * ncols; i += kBlock) lds[i] = 0.0;
+  for (int i = threadIdx.x; i < 4 * nacc; i += kBlock) lds[i] = 0.0;
   __syncthreads();
   const double a = tt.uk ? *tt.a : 0.0;
   const double b = (tt.uk && tt.ukm1) ? *tt.b : 0.0;
-  double* wave_acc = lds + wave * ncols;
+  double* wave_acc = lds + wave * nacc;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t base = tile * kTileRows + 2 * threadIdx.x;
     if ((tile + 1) * kTileRows <= n)
-      dots_tile<true>(src, tt, a, b, cs, ncols, base, n, wave_acc);
+      dots_tile<true, CPLX>(src, tt, a, b, cs, ncols, base, n, wave_acc);
     else
-      dots_tile<false>(src, tt, a, b, cs, ncols, base, n, wave_acc);
+      dots_tile<false, CPLX>(src, tt, a, b, cs, ncols, base, n, wave_acc);
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < ncols; c += kBlock)
-    partials[(int64_t)c * pstride + blockIdx.x] = (lds[c] + lds[ncols + c]) + (lds[2 * ncols + c] + lds[3 * ncols + c]);
+  for (int c = threadIdx.x; c < nacc; c += kBlock)
+    partials[(int64_t)c * pstride + blockIdx.x] = (lds[c] + lds[nacc + c]) + (lds[2 * nacc + c] + lds[3 * nacc + c]);
 }
 
 // ---------------------------------------------------------------------------
 // update: dst = w0 - sum_c h_c * col_c (c ascending, the reference's order of
 // subtraction), fused ||dst||^2.  Second pass over the selected part of the slab.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void axmy8(double2 (&w)[4], double h, const double2 (&x)[4]) {
+template <bool CPLX>
+__device__ __forceinline__ void axmy8(double2 (&w)[4], const double* __restrict__ h, int ci, const double2 (&x)[4]) {
+  if (!CPLX) {
+    const double hr = h[ci];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    w[i].x = fma(-h, x[i].x, w[i].x);
-    w[i].y = fma(-h, x[i].y, w[i].y);
+    for (int i = 0; i < 4; ++i) {
+      w[i].x = fma(-hr, x[i].x, w[i].x);
+      w[i].y = fma(-hr, x[i].y, w[i].y);
+    }
+  } else {  // w -= (hr + i hi) * (x.x + i x.y)
+    const double hr = h[2 * ci], hi = h[2 * ci + 1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      w[i].x = fma(hi, x[i].y, fma(-hr, x[i].x, w[i].x));
+      w[i].y = fma(-hi, x[i].x, fma(-hr, x[i].y, w[i].y));
+    }
   }
 }
 
-template <bool FULL>
+template <bool FULL, bool CPLX>
 __device__ __forceinline__ double update_tile(const double* src, double* dst,  // may alias (in-place update)
                                               const ThreeTerm& tt, double a, double b, const ColumnSet& cs, int ncols,
                                               const double* __restrict__ h, int64_t base, int64_t n) {
@@ -176,15 +222,15 @@ __device__ __forceinline__ double update_tile(const double* src, double* dst,  /
     load_col<FULL>(x1, column_ptr(cs, ci + 1), base, n);
     load_col<FULL>(x2, column_ptr(cs, ci + 2), base, n);
     load_col<FULL>(x3, column_ptr(cs, ci + 3), base, n);
-    axmy8(w, h[ci + 0], x0);
-    axmy8(w, h[ci + 1], x1);
-    axmy8(w, h[ci + 2], x2);
-    axmy8(w, h[ci + 3], x3);
+    axmy8<CPLX>(w, h, ci + 0, x0);
+    axmy8<CPLX>(w, h, ci + 1, x1);
+    axmy8<CPLX>(w, h, ci + 2, x2);
+    axmy8<CPLX>(w, h, ci + 3, x3);
   }
   for (; ci < ncols; ++ci) {
     double2 x0[4];
     load_col<FULL>(x0, column_ptr(cs, ci), base, n);
-    axmy8(w, h[ci], x0);
+    axmy8<CPLX>(w, h, ci, x0);
   }
   double nrm = 0.0;
 #pragma unroll
@@ -199,6 +245,7 @@ __device__ __forceinline__ double update_tile(const double* src, double* dst,  /
   return nrm;
 }
 
+template <bool CPLX>
 __global__ __launch_bounds__(kBlock) void k_update(const double* src, double* dst, ThreeTerm tt, ColumnSet cs,
                                                    const double* __restrict__ h, int64_t n, int64_t ntiles,
                                                    double* __restrict__ partials, const Ctrl* __restrict__ ctrl) {
@@ -211,9 +258,9 @@ __global__ __launch_bounds__(kBlock) void k_update(const double* src, double* ds
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t base = tile * kTileRows + 2 * threadIdx.x;
     if ((tile + 1) * kTileRows <= n)
-      nrm += update_tile<true>(src, dst, tt, a, b, cs, ncols, h, base, n);
+      nrm += update_tile<true, CPLX>(src, dst, tt, a, b, cs, ncols, h, base, n);
     else
-      nrm += update_tile<false>(src, dst, tt, a, b, cs, ncols, h, base, n);
+      nrm += update_tile<false, CPLX>(src, dst, tt, a, b, cs, ncols, h, base, n);
   }
   nrm = block_sum(nrm, lds4);
   if (threadIdx.x == 0) partials[blockIdx.x] = nrm;
@@ -311,6 +358,99 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int32_t* __restrict__ row
   }
 }
 
+// Complex fp64 variant (the scalar type of the reference's own samples): entries, x and
+// products are 16-byte (re, im) pairs; 1024 products per LDS chunk.  Same two phases, same
+// stored-order accumulation; products use separate multiplies and adds (no contraction),
+// like a plain C complex multiply.  shift is complex (ArnoldiBase::eigenvalueShift_ is a
+// Scalar, arnoldi.hpp:108); partials hold (re, im) of conj(u).y.
+constexpr int kSpmvChunkZ = 1024;
+__device__ __forceinline__ int skewz(int i) { return i + (i >> 4); }
+
+__device__ __forceinline__ double2 cmul_nofma(double2 a, double2 b) {
+#pragma clang fp contract(off)
+  double2 r;
+  r.x = a.x * b.x - a.y * b.y;
+  r.y = a.x * b.y + a.y * b.x;
+  return r;
+}
+
+__global__ __launch_bounds__(kBlock) void k_spmv_z(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                   const double2* __restrict__ val, const double2* __restrict__ x_ext,
+                                                   const double* __restrict__ scale_ptr, double shift_re,
+                                                   double shift_im, double2* __restrict__ y,
+                                                   double2* __restrict__ u_out, int64_t n, int64_t ntiles,
+                                                   double* __restrict__ partials, int pstride,
+                                                   const Ctrl* __restrict__ ctrl) {
+  __shared__ double2 prod[kSpmvChunkZ + kSpmvChunkZ / 16 + 8];
+  __shared__ double lds4[4];
+  if (ctrl->stopped) return;
+  const double scale = scale_ptr ? *scale_ptr : 1.0;
+  const int tid = threadIdx.x;
+  const bool has_shift = shift_re != 0.0 || shift_im != 0.0;
+  double dr = 0.0, di = 0.0;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t r0 = tile * kSpmvRows;
+    const int64_t r = r0 + tid;
+    int rs = 0, re = 0;
+    if (r < n) {
+      rs = rowptr[r];
+      re = rowptr[r + 1];
+    }
+    const int64_t rend = (r0 + kSpmvRows < n) ? r0 + kSpmvRows : n;
+    const int p0 = rowptr[r0];
+    const int p1 = rowptr[rend];
+    const int pa = p0 & ~3;
+    double2 sum = make_double2(0.0, 0.0);
+    for (int cb = pa; cb < p1; cb += kSpmvChunkZ) {
+      const int cend = (cb + kSpmvChunkZ < p1) ? cb + kSpmvChunkZ : p1;
+      for (int q = cb + 4 * tid; q < cend; q += 4 * kBlock) {
+        const int4 c4 = *reinterpret_cast<const int4*>(col + q);
+        const double2 v0 = val[q], v1 = val[q + 1], v2 = val[q + 2], v3 = val[q + 3];
+        double2 x0 = x_ext[c4.x], x1 = x_ext[c4.y], x2 = x_ext[c4.z], x3 = x_ext[c4.w];
+        x0.x *= scale, x0.y *= scale, x1.x *= scale, x1.y *= scale;
+        x2.x *= scale, x2.y *= scale, x3.x *= scale, x3.y *= scale;
+        const int li = q - cb;
+        prod[skewz(li + 0)] = cmul_nofma(v0, x0);
+        prod[skewz(li + 1)] = cmul_nofma(v1, x1);
+        prod[skewz(li + 2)] = cmul_nofma(v2, x2);
+        prod[skewz(li + 3)] = cmul_nofma(v3, x3);
+      }
+      __syncthreads();
+      const int lo = rs > cb ? rs : cb;
+      const int hi = re < cend ? re : cend;
+      for (int p = lo; p < hi; ++p) {
+        const double2 t = prod[skewz(p - cb)];
+        sum.x = sum.x + t.x;
+        sum.y = sum.y + t.y;
+      }
+      __syncthreads();
+    }
+    if (r < n) {
+      double2 xr = x_ext[r];
+      xr.x *= scale;
+      xr.y *= scale;
+      double2 yr = sum;
+      if (has_shift) {
+        const double2 t = cmul_nofma(make_double2(shift_re, shift_im), xr);
+        yr.x = yr.x + t.x;
+        yr.y = yr.y + t.y;
+      }
+      y[r] = yr;
+      if (u_out) u_out[r] = xr;
+      dr = fma(xr.x, yr.x, fma(xr.y, yr.y, dr));   // conj(u) * y
+      di = fma(xr.x, yr.y, fma(-xr.y, yr.x, di));
+    }
+  }
+  if (partials) {
+    dr = block_sum(dr, lds4);
+    di = block_sum(di, lds4);
+    if (tid == 0) {
+      partials[blockIdx.x] = dr;
+      partials[pstride + blockIdx.x] = di;
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void k_scale(const double* __restrict__ x, const double* __restrict__ scale_dev,
                                                   double scale_host, double* __restrict__ out, int64_t n,
                                                   const Ctrl* __restrict__ ctrl) {
@@ -339,12 +479,42 @@ __global__ __launch_bounds__(kBlock) void k_shift_dot(double* __restrict__ y, co
   if (threadIdx.x == 0) partials[blockIdx.x] = dot;
 }
 
+// complex: y += shift*u, partials = (re, im) of conj(u).y
+__global__ __launch_bounds__(kBlock) void k_shift_dot_z(double2* __restrict__ y, const double2* __restrict__ u,
+                                                        double shift_re, double shift_im, int64_t n,
+                                                        double* __restrict__ partials, int pstride,
+                                                        const Ctrl* __restrict__ ctrl) {
+  __shared__ double lds4[4];
+  if (ctrl->stopped) return;
+  const bool has_shift = shift_re != 0.0 || shift_im != 0.0;
+  double dr = 0.0, di = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const double2 ui = u[i];
+    double2 yi = y[i];
+    if (has_shift) {
+      const double2 t = cmul_nofma(make_double2(shift_re, shift_im), ui);
+      yi.x = yi.x + t.x;
+      yi.y = yi.y + t.y;
+      y[i] = yi;
+    }
+    dr = fma(ui.x, yi.x, fma(ui.y, yi.y, dr));
+    di = fma(ui.x, yi.y, fma(-ui.y, yi.x, di));
+  }
+  dr = block_sum(dr, lds4);
+  di = block_sum(di, lds4);
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x] = dr;
+    partials[pstride + blockIdx.x] = di;
+  }
+}
+
+// es = doubles per entry (1 real, 2 complex)
 __global__ __launch_bounds__(kBlock) void k_pack(const double* __restrict__ x, const int32_t* __restrict__ idx,
-                                                 int64_t count, double* __restrict__ out,
+                                                 int64_t count, int es, double* __restrict__ out,
                                                  const Ctrl* __restrict__ ctrl) {
   if (ctrl && ctrl->stopped) return;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += (int64_t)gridDim.x * kBlock)
-    out[i] = x[idx[i]];
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < count * es; i += (int64_t)gridDim.x * kBlock)
+    out[i] = x[(int64_t)idx[i / es] * es + (i % es)];
 }
 
 __global__ void k_sum_shards(PtrPack bufs, int nshards, int n) {
@@ -384,7 +554,7 @@ __global__ void k_fin_alpha(Ctrl* ctrl, const double* val, double* alpha, int fi
   if (!first) ctrl->iterations++;  // lanczos.hpp:450 (not on the first call, :378-398)
 }
 
-__global__ void k_arnoldi_begin(Ctrl* ctrl, double threshold, int64_t n_global, int cap, double* H, int ldh) {
+__global__ void k_arnoldi_begin(Ctrl* ctrl, double threshold, int64_t n_global, int cap, double* H, int ldh, int es) {
   if (threadIdx.x != 0 || ctrl->stopped) return;
   const int k = ctrl->nvec;
   // arnoldiStepIsUtmost  arnoldi.hpp:277-288
@@ -392,17 +562,17 @@ __global__ void k_arnoldi_begin(Ctrl* ctrl, double threshold, int64_t n_global, 
     ctrl->stopped = 1;
     return;
   }
-  H[(int64_t)(k - 1) * ldh + k] = ctrl->residue;  // arnoldi.hpp:363
-  ctrl->scale = 1.0 / ctrl->residue;              // arnoldi.hpp:365
+  H[((int64_t)(k - 1) * ldh + k) * es] = ctrl->residue;  // arnoldi.hpp:363 (imaginary part stays 0)
+  ctrl->scale = 1.0 / ctrl->residue;                     // arnoldi.hpp:365
 }
 
-__global__ void k_arnoldi_end(Ctrl* ctrl, const double* h, double* H, int ldh) {
+__global__ void k_arnoldi_end(Ctrl* ctrl, const double* h, double* H, int ldh, int es) {
   if (ctrl->stopped) return;
   const int k = ctrl->nvec;  // index of the vector just added
-  for (int i = threadIdx.x; i <= k; i += blockDim.x) H[(int64_t)k * ldh + i] = h[i];  // arnoldi.hpp:380-383
+  for (int i = threadIdx.x; i < (k + 1) * es; i += blockDim.x) H[(int64_t)k * ldh * es + i] = h[i];  // arnoldi.hpp:380-383
   __syncthreads();
   if (threadIdx.x == 0) {
-    H[(int64_t)k * ldh + k + 1] = 0.0;  // arnoldi.hpp:384
+    for (int e = 0; e < es; ++e) H[((int64_t)k * ldh + k + 1) * es + e] = 0.0;  // arnoldi.hpp:384
     ctrl->nvec = k + 1;
     ctrl->nalpha = k + 1;
     ctrl->iterations++;
@@ -513,18 +683,22 @@ __global__ __launch_bounds__(kBlock) void k_ritz(const double* __restrict__ V, i
   }
 }
 
-// first local row with |x| > 0 per column: out[2e] = index (n if none), out[2e+1] = value
-__global__ __launch_bounds__(kBlock) void k_first_nonzero(const double* __restrict__ X, int64_t ldx, int64_t n,
+// first local entry with |z| > 0 per column: out[3e] = entry index (n if none), out[3e+1..3e+2] = (re, im).
+// es = doubles per entry; ldx in doubles.
+__global__ __launch_bounds__(kBlock) void k_first_nonzero(const double* __restrict__ X, int64_t ldx, int64_t n, int es,
                                                           double* __restrict__ out) {
   __shared__ long long best[kBlock];
   const double* x = X + (int64_t)blockIdx.x * ldx;
   long long found = n;
-  // chunks of 256*16 rows in order; stop at the first chunk that has a hit
+  // chunks of 256*16 entries in order; stop at the first chunk that has a hit
   for (int64_t c0 = 0; c0 < n && found == n; c0 += kBlock * 16) {
     long long mine = n;
     for (int j = 0; j < 16; ++j) {
       const int64_t i = c0 + j * kBlock + threadIdx.x;
-      if (i < n && fabs(x[i]) > 0.0 && i < mine) mine = i;
+      if (i < n && i < mine) {
+        const bool nz = es == 1 ? fabs(x[i]) > 0.0 : (fabs(x[2 * i]) > 0.0 || fabs(x[2 * i + 1]) > 0.0);
+        if (nz) mine = i;
+      }
     }
     best[threadIdx.x] = mine;
     __syncthreads();
@@ -536,30 +710,51 @@ __global__ __launch_bounds__(kBlock) void k_first_nonzero(const double* __restri
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    out[2 * blockIdx.x] = (double)found;
-    out[2 * blockIdx.x + 1] = found < n ? x[found] : 0.0;
+    out[3 * blockIdx.x] = (double)found;
+    out[3 * blockIdx.x + 1] = found < n ? x[found * es] : 0.0;
+    out[3 * blockIdx.x + 2] = (found < n && es == 2) ? x[found * es + 1] : 0.0;
   }
 }
 
-__global__ __launch_bounds__(kBlock) void k_scale_columns(double* __restrict__ X, int64_t ldx, int64_t n,
+// column e *= (factors[2e] + i factors[2e+1])  (real columns use the real part only)
+__global__ __launch_bounds__(kBlock) void k_scale_columns(double* __restrict__ X, int64_t ldx, int64_t n, int es,
                                                           const double* __restrict__ factors) {
   double* x = X + (int64_t)blockIdx.y * ldx;
-  const double f = factors[blockIdx.y];
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) x[i] *= f;
+  const double fr = factors[2 * blockIdx.y], fi = factors[2 * blockIdx.y + 1];
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    if (es == 1) {
+      x[i] *= fr;
+    } else {
+      const double a = x[2 * i], b = x[2 * i + 1];
+      x[2 * i] = a * fr - b * fi;
+      x[2 * i + 1] = a * fi + b * fr;
+    }
+  }
 }
 
-// complex Ritz vectors: out[(i + e*ld)*2 + {0,1}] = (X[:,2e] + i X[:,2e+1]) * (fr + i fi)
-__global__ __launch_bounds__(kBlock) void k_complex_finish(const double* __restrict__ X, int64_t ldx, int64_t n,
-                                                           const double* __restrict__ factors,
-                                                           double* __restrict__ out, int64_t ldo) {
-  const int e = blockIdx.y;
-  const double fr = factors[2 * e], fi = factors[2 * e + 1];
-  const double* xr = X + (int64_t)(2 * e) * ldx;
-  const double* xi = xr + ldx;
-  double2* o = reinterpret_cast<double2*>(out) + (int64_t)e * ldo;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-    const double a = xr[i], b = xi[i];
-    o[i] = make_double2(a * fr - b * fi, a * fi + b * fr);
+// Ritz vectors with complex coefficients: raw columns 2e (V*s_re) and 2e+1 (V*s_im) -> out column e
+// (interleaved complex, ldo entries): x = Xa + i Xb.  Real basis: (Xa[i], Xb[i]); complex basis:
+// (Xa.re - Xb.im, Xa.im + Xb.re).  partials[e*pstride + block] = partial ||x||^2.
+__global__ __launch_bounds__(kBlock) void k_ritz_combine(const double* __restrict__ X, int64_t ldx, int nc, int64_t n,
+                                                         int es, double* __restrict__ out, int64_t ldo,
+                                                         double* __restrict__ partials, int pstride) {
+  __shared__ double lds4[4];
+  for (int e = 0; e < nc; ++e) {
+    const double* xa = X + (int64_t)(2 * e) * ldx;
+    const double* xb = xa + ldx;
+    double2* o = reinterpret_cast<double2*>(out) + (int64_t)e * ldo;
+    double nrm = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+      double2 z;
+      if (es == 1)
+        z = make_double2(xa[i], xb[i]);
+      else
+        z = make_double2(xa[2 * i] - xb[2 * i + 1], xa[2 * i + 1] + xb[2 * i]);
+      o[i] = z;
+      nrm = fma(z.x, z.x, fma(z.y, z.y, nrm));
+    }
+    nrm = block_sum(nrm, lds4);
+    if (threadIdx.x == 0) partials[(int64_t)e * pstride + blockIdx.x] = nrm;
   }
 }
 
@@ -576,18 +771,39 @@ int grid_for_tiles(int64_t ntiles, int blocks_per_cu) {
 void set_num_cu(int n) { g_num_cu = n > 0 ? n : 256; }
 
 void launch_dots(hipStream_t s, const double* src, ThreeTerm tt, ColumnSet cs, int64_t n, double* partials,
-                 int pstride, int grid, const Ctrl* ctrl) {
+                 int pstride, int grid, const Ctrl* ctrl, bool cplx) {
   const int ncols = cs.count + cs.nq;
   if (ncols <= 0) return;
   const int64_t ntiles = (n + kTileRows - 1) / kTileRows;
-  const size_t shmem = (size_t)4 * ncols * sizeof(double);
-  hipLaunchKernelGGL(k_dots, dim3(grid), dim3(kBlock), shmem, s, src, tt, cs, n, ntiles, partials, pstride, ctrl);
+  const size_t shmem = (size_t)4 * ncols * (cplx ? 2 : 1) * sizeof(double);
+  if (cplx)
+    hipLaunchKernelGGL(k_dots<true>, dim3(grid), dim3(kBlock), shmem, s, src, tt, cs, n, ntiles, partials, pstride, ctrl);
+  else
+    hipLaunchKernelGGL(k_dots<false>, dim3(grid), dim3(kBlock), shmem, s, src, tt, cs, n, ntiles, partials, pstride, ctrl);
 }
 
 void launch_update(hipStream_t s, const double* src, double* dst, ThreeTerm tt, ColumnSet cs, const double* h,
-                   int64_t n, double* partials, int grid, const Ctrl* ctrl) {
+                   int64_t n, double* partials, int grid, const Ctrl* ctrl, bool cplx) {
   const int64_t ntiles = (n + kTileRows - 1) / kTileRows;
-  hipLaunchKernelGGL(k_update, dim3(grid), dim3(kBlock), 0, s, src, dst, tt, cs, h, n, ntiles, partials, ctrl);
+  if (cplx)
+    hipLaunchKernelGGL(k_update<true>, dim3(grid), dim3(kBlock), 0, s, src, dst, tt, cs, h, n, ntiles, partials, ctrl);
+  else
+    hipLaunchKernelGGL(k_update<false>, dim3(grid), dim3(kBlock), 0, s, src, dst, tt, cs, h, n, ntiles, partials, ctrl);
+}
+
+void launch_spmv_z(hipStream_t s, const int32_t* rowptr, const int32_t* col, const double* val, const double* x_ext,
+                   const double* scale, double shift_re, double shift_im, double* y, double* u_out, int64_t n,
+                   double* partials, int pstride, int grid, const Ctrl* ctrl) {
+  const int64_t ntiles = (n + kSpmvRows - 1) / kSpmvRows;
+  hipLaunchKernelGGL(k_spmv_z, dim3(grid), dim3(kBlock), 0, s, rowptr, col, reinterpret_cast<const double2*>(val),
+                     reinterpret_cast<const double2*>(x_ext), scale, shift_re, shift_im, reinterpret_cast<double2*>(y),
+                     reinterpret_cast<double2*>(u_out), n, ntiles, partials, pstride, ctrl);
+}
+
+void launch_shift_dot_z(hipStream_t s, double* y, const double* u, double shift_re, double shift_im, int64_t n,
+                        double* partials, int pstride, int grid, const Ctrl* ctrl) {
+  hipLaunchKernelGGL(k_shift_dot_z, dim3(grid), dim3(kBlock), 0, s, reinterpret_cast<double2*>(y),
+                     reinterpret_cast<const double2*>(u), shift_re, shift_im, n, partials, pstride, ctrl);
 }
 
 void launch_reduce(hipStream_t s, const double* partials, int pstride, int nblocks, int ncols, double* out,
@@ -615,10 +831,11 @@ void launch_shift_dot(hipStream_t s, double* y, const double* u, double shift, i
   hipLaunchKernelGGL(k_shift_dot, dim3(grid), dim3(kBlock), 0, s, y, u, shift, n, partials, ctrl);
 }
 
-void launch_pack(hipStream_t s, const double* x, const int32_t* idx, int64_t count, double* out, const Ctrl* ctrl) {
+void launch_pack(hipStream_t s, const double* x, const int32_t* idx, int64_t count, int es, double* out,
+                 const Ctrl* ctrl) {
   if (count <= 0) return;
-  const int grid = grid_for_tiles((count + kBlock - 1) / kBlock, 8);
-  hipLaunchKernelGGL(k_pack, dim3(grid), dim3(kBlock), 0, s, x, idx, count, out, ctrl);
+  const int grid = grid_for_tiles((count * es + kBlock - 1) / kBlock, 8);
+  hipLaunchKernelGGL(k_pack, dim3(grid), dim3(kBlock), 0, s, x, idx, count, es, out, ctrl);
 }
 
 void launch_sum_shards(hipStream_t s, const PtrPack& bufs, int nshards, int n) {
@@ -635,12 +852,12 @@ void launch_fin_alpha(hipStream_t s, Ctrl* ctrl, const double* val, double* alph
 }
 
 void launch_arnoldi_begin(hipStream_t s, Ctrl* ctrl, double threshold, int64_t n_global, int cap, double* H,
-                          int ldh) {
-  hipLaunchKernelGGL(k_arnoldi_begin, dim3(1), dim3(64), 0, s, ctrl, threshold, n_global, cap, H, ldh);
+                          int ldh, int es) {
+  hipLaunchKernelGGL(k_arnoldi_begin, dim3(1), dim3(64), 0, s, ctrl, threshold, n_global, cap, H, ldh, es);
 }
 
-void launch_arnoldi_end(hipStream_t s, Ctrl* ctrl, const double* h, double* H, int ldh) {
-  hipLaunchKernelGGL(k_arnoldi_end, dim3(1), dim3(kBlock), 0, s, ctrl, h, H, ldh);
+void launch_arnoldi_end(hipStream_t s, Ctrl* ctrl, const double* h, double* H, int ldh, int es) {
+  hipLaunchKernelGGL(k_arnoldi_end, dim3(1), dim3(kBlock), 0, s, ctrl, h, H, ldh, es);
 }
 
 void launch_accept_vector(hipStream_t s, Ctrl* ctrl) {
@@ -662,19 +879,18 @@ void launch_ritz(hipStream_t s, const double* V, int64_t ldv, int nvec, const do
                      partials, pstride);
 }
 
-void launch_first_nonzero(hipStream_t s, const double* X, int64_t ldx, int nev, int64_t n, double* out_idx_val) {
-  hipLaunchKernelGGL(k_first_nonzero, dim3(nev), dim3(kBlock), 0, s, X, ldx, n, out_idx_val);
+void launch_first_nonzero(hipStream_t s, const double* X, int64_t ldx, int ncol, int64_t n, int es, double* out) {
+  hipLaunchKernelGGL(k_first_nonzero, dim3(ncol), dim3(kBlock), 0, s, X, ldx, n, es, out);
 }
 
-void launch_complex_finish(hipStream_t s, const double* X, int64_t ldx, int ncomplex, int64_t n,
-                           const double* factors_dev, double* out, int64_t ldo) {
+void launch_scale_columns(hipStream_t s, double* X, int64_t ldx, int ncol, int64_t n, int es, const double* factors_dev) {
   const int gx = grid_for_tiles((n + kBlock - 1) / kBlock, 4);
-  hipLaunchKernelGGL(k_complex_finish, dim3(gx, ncomplex), dim3(kBlock), 0, s, X, ldx, n, factors_dev, out, ldo);
+  hipLaunchKernelGGL(k_scale_columns, dim3(gx, ncol), dim3(kBlock), 0, s, X, ldx, n, es, factors_dev);
 }
 
-void launch_scale_columns(hipStream_t s, double* X, int64_t ldx, int nev, int64_t n, const double* factors_dev) {
-  const int gx = grid_for_tiles((n + kBlock - 1) / kBlock, 4);
-  hipLaunchKernelGGL(k_scale_columns, dim3(gx, nev), dim3(kBlock), 0, s, X, ldx, n, factors_dev);
+void launch_ritz_combine(hipStream_t s, const double* X, int64_t ldx, int nc, int64_t n, int es, double* out,
+                         int64_t ldo, double* partials, int pstride, int grid) {
+  hipLaunchKernelGGL(k_ritz_combine, dim3(grid), dim3(kBlock), 0, s, X, ldx, nc, n, es, out, ldo, partials, pstride);
 }
 
 }  // namespace eigenex

@@ -46,11 +46,19 @@ int grid_for_tiles(int64_t ntiles, int blocks_per_cu);
 void set_num_cu(int n);
 
 // partials[c*pstride + block], c < ncols: per-block partial dot of w0 with column c
+// Vector lengths `n` of dots/update are in DOUBLES (a complex vector of N entries = 2N interleaved doubles);
+// cplx selects conjugate-linear complex arithmetic; complex partials occupy rows 2c (re) and 2c+1 (im).
 void launch_dots(hipStream_t s, const double* src, ThreeTerm tt, ColumnSet cs, int64_t n, double* partials,
-                 int pstride, int grid, const Ctrl* ctrl);
+                 int pstride, int grid, const Ctrl* ctrl, bool cplx);
 // dst = w0 - sum_c h[c]*col_c (sequential in c); partials[block] = partial ||dst||^2
 void launch_update(hipStream_t s, const double* src, double* dst, ThreeTerm tt, ColumnSet cs, const double* h,
-                   int64_t n, double* partials, int grid, const Ctrl* ctrl);
+                   int64_t n, double* partials, int grid, const Ctrl* ctrl, bool cplx);
+// complex operator: n = rows; val/x/y/u_out interleaved (re, im); partials[block] = re, partials[pstride+block] = im of conj(u).y
+void launch_spmv_z(hipStream_t s, const int32_t* rowptr, const int32_t* col, const double* val, const double* x_ext,
+                   const double* scale, double shift_re, double shift_im, double* y, double* u_out, int64_t n,
+                   double* partials, int pstride, int grid, const Ctrl* ctrl);
+void launch_shift_dot_z(hipStream_t s, double* y, const double* u, double shift_re, double shift_im, int64_t n,
+                        double* partials, int pstride, int grid, const Ctrl* ctrl);
 // out[c] = sum_b partials[c*pstride + b], fixed order (deterministic second stage)
 void launch_reduce(hipStream_t s, const double* partials, int pstride, int nblocks, int ncols, double* out,
                    const Ctrl* ctrl);
@@ -65,7 +73,8 @@ void launch_scale(hipStream_t s, const double* x, const double* scale_dev, doubl
 void launch_shift_dot(hipStream_t s, double* y, const double* u, double shift, int64_t n, double* partials, int grid,
                       const Ctrl* ctrl);
 // gather send buffer: out[i] = x[idx[i]]
-void launch_pack(hipStream_t s, const double* x, const int32_t* idx, int64_t count, double* out, const Ctrl* ctrl);
+void launch_pack(hipStream_t s, const double* x, const int32_t* idx, int64_t count, int es, double* out,
+                 const Ctrl* ctrl);
 // loopback all-reduce: every p[s][i] = sum_s p[s][i] (fixed order); pointers travel as kernel arguments
 constexpr int kMaxLoopbackShards = 64;
 struct PtrPack {
@@ -82,9 +91,10 @@ void launch_fin_norm(hipStream_t s, Ctrl* ctrl, const double* nrm2, double thres
 // Lanczos: alpha.push_back(*val); counts as a successful call; first==1: no iteration increment
 void launch_fin_alpha(hipStream_t s, Ctrl* ctrl, const double* val, double* alpha, int first, int cap);
 // Arnoldi start of a later call: stop if residue <= threshold or basis full, else H[k][k-1] = residue, scale = 1/residue
-void launch_arnoldi_begin(hipStream_t s, Ctrl* ctrl, double threshold, int64_t n_global, int cap, double* H, int ldh);
+void launch_arnoldi_begin(hipStream_t s, Ctrl* ctrl, double threshold, int64_t n_global, int cap, double* H, int ldh,
+                          int es);
 // Arnoldi end of a call: H[0..k][k] = h[0..k], H[k+1][k] = 0, ++iterations
-void launch_arnoldi_end(hipStream_t s, Ctrl* ctrl, const double* h, double* H, int ldh);
+void launch_arnoldi_end(hipStream_t s, Ctrl* ctrl, const double* h, double* H, int ldh, int es);
 // vector accepted into the basis: ++nvec  (after the operator has been applied with `scale`)
 void launch_accept_vector(hipStream_t s, Ctrl* ctrl);
 
@@ -95,11 +105,13 @@ void launch_laplacian3d(hipStream_t s, int64_t n, int64_t rb, int64_t re, int64_
 // Ritz vectors: X[:, e] = sum_m S[m + e*lds] * V[:, m]  for e < nev (<= 8 per launch); partial norms
 void launch_ritz(hipStream_t s, const double* V, int64_t ldv, int nvec, const double* S_dev, int lds, int nev,
                  double* X, int64_t ldx, int64_t n, double* partials, int pstride, int grid);
-// per column: first local index with a non-zero entry (n if none) and its value
-void launch_first_nonzero(hipStream_t s, const double* X, int64_t ldx, int nev, int64_t n, double* out_idx_val);
-void launch_scale_columns(hipStream_t s, double* X, int64_t ldx, int nev, int64_t n, const double* factors_dev);
-// out (interleaved re,im; column e at out + 2*e*ldo) = (X[:,2e] + i X[:,2e+1]) * (factors[2e] + i factors[2e+1])
-void launch_complex_finish(hipStream_t s, const double* X, int64_t ldx, int ncomplex, int64_t n,
-                           const double* factors_dev, double* out, int64_t ldo);
+// per column: first local ENTRY with |z| > 0 (n if none) and its value: out[3e] = index, out[3e+1..2] = (re, im);
+// es = doubles per entry, ldx in doubles
+void launch_first_nonzero(hipStream_t s, const double* X, int64_t ldx, int ncol, int64_t n, int es, double* out);
+// column e *= factors[2e] + i*factors[2e+1] (real columns: real part only)
+void launch_scale_columns(hipStream_t s, double* X, int64_t ldx, int ncol, int64_t n, int es, const double* factors_dev);
+// complex coefficients: out column e = X[:,2e] + i*X[:,2e+1] (basis real or complex), partial squared norms
+void launch_ritz_combine(hipStream_t s, const double* X, int64_t ldx, int nc, int64_t n, int es, double* out,
+                         int64_t ldo, double* partials, int pstride, int grid);
 
 }  // namespace eigenex

@@ -147,6 +147,7 @@ struct Segment {  // one contiguous piece of a halo exchange with one peer
 struct CsrShard {
   int gshard = 0;
   int64_t rb = 0, re = 0, nloc = 0, npad = 0, nnz = 0, nhalo = 0;
+  int es = 1;  // doubles per stored value: 1 real, 2 complex (re, im interleaved)
   int32_t* rowptr = nullptr;
   int32_t* col = nullptr;
   double* val = nullptr;
@@ -162,6 +163,7 @@ struct CsrShard {
 struct eigenex_csr_s {
   eigenex_context_s* ctx = nullptr;
   int64_t n_global = 0;
+  int es = 1;
   std::vector<CsrShard> sh;
 };
 
@@ -170,6 +172,8 @@ namespace {
 struct BasisShard {
   int gshard = 0;
   int64_t rb = 0, nloc = 0, ldv = 0, nhalo = 0;
+  int es = 1;              // doubles per entry (1 real, 2 complex)
+  int64_t nd = 0, ldd = 0;  // vector length / column stride in doubles (= nloc*es, ldv*es)
   CsrShard* csr = nullptr;
   double *V = nullptr, *Q = nullptr, *v = nullptr, *w = nullptr, *start = nullptr;
   double *partials = nullptr, *hbuf = nullptr, *alpha = nullptr, *beta = nullptr, *H = nullptr;
@@ -186,7 +190,8 @@ struct eigenex_basis_s {
   eigenex_csr_s* csr = nullptr;
   int64_t n_global = 0;
   int cap = 0, nq = 0, maxcols = 0, ldh = 0;
-  double shift = 0.0, threshold = 1e-12;
+  int es = 1;
+  double shift = 0.0, shift_im = 0.0, threshold = 1e-12;
   int64_t interval = 1;
   int ortho_mode = EIGENEX_ORTHO_BATCHED;
   std::vector<BasisShard> sh;
@@ -196,10 +201,11 @@ struct eigenex_basis_s {
   void* fn_user = nullptr;
   double *pin_in = nullptr, *pin_out = nullptr;
   Ctrl* pin_ctrl = nullptr;
-  int slot_nrm() const { return maxcols; }
-  int slot_alpha() const { return maxcols + 1; }
-  int slot_a() const { return maxcols + 2; }
-  int slot_b() const { return maxcols + 3; }
+  // offsets (in doubles) into hbuf behind the es*maxcols coefficient entries
+  int slot_nrm() const { return es * maxcols; }
+  int slot_alpha() const { return es * maxcols + 1; }  // (re, im) for complex
+  int slot_a() const { return es * maxcols + 4; }
+  int slot_b() const { return es * maxcols + 5; }
 };
 
 namespace {
@@ -233,7 +239,7 @@ int halo_exchange(eigenex_basis_s* b, bool use_ctrl = true) {
     CsrShard* cs = bs.csr;
     for (auto& sg : cs->send)
       if (sg.contig_start < 0)
-        launch_pack(c->stream, bs.w, cs->send_idx + sg.offset, sg.count, cs->sendbuf + sg.offset,
+        launch_pack(c->stream, bs.w, cs->send_idx + sg.offset, sg.count, bs.es, cs->sendbuf + sg.offset * bs.es,
                     use_ctrl ? bs.ctrl : bs.ctrl_zero);
   }
   if (c->loopback) {
@@ -245,9 +251,9 @@ int halo_exchange(eigenex_basis_s* b, bool use_ctrl = true) {
         for (auto& x : src.csr->send)
           if (x.peer == bs.gshard) sg = &x;
         if (!sg || sg->count != rg.count) return fail(EIGENEX_ERR_STATE, "halo plan mismatch");
-        const double* sp = sg->contig_start >= 0 ? src.w + sg->contig_start : src.csr->sendbuf + sg->offset;
-        HIPCHK(hipMemcpyAsync(bs.w + bs.ldv + rg.offset, sp, sizeof(double) * rg.count, hipMemcpyDeviceToDevice,
-                              c->stream));
+        const double* sp = sg->contig_start >= 0 ? src.w + sg->contig_start * src.es : src.csr->sendbuf + sg->offset * src.es;
+        HIPCHK(hipMemcpyAsync(bs.w + (bs.ldv + rg.offset) * bs.es, sp, sizeof(double) * rg.count * bs.es,
+                              hipMemcpyDeviceToDevice, c->stream));
       }
     }
     return 0;
@@ -257,11 +263,11 @@ int halo_exchange(eigenex_basis_s* b, bool use_ctrl = true) {
   if (cs->send.empty() && cs->recv.empty()) return 0;
   NCCLCHK(ncclGroupStart());
   for (auto& sg : cs->send) {
-    const double* sp = sg.contig_start >= 0 ? bs.w + sg.contig_start : cs->sendbuf + sg.offset;
-    NCCLCHK(ncclSend(sp, (size_t)sg.count, ncclDouble, sg.peer, c->comm, c->stream));
+    const double* sp = sg.contig_start >= 0 ? bs.w + sg.contig_start * bs.es : cs->sendbuf + sg.offset * bs.es;
+    NCCLCHK(ncclSend(sp, (size_t)sg.count * bs.es, ncclDouble, sg.peer, c->comm, c->stream));
   }
   for (auto& rg : cs->recv)
-    NCCLCHK(ncclRecv(bs.w + bs.ldv + rg.offset, (size_t)rg.count, ncclDouble, rg.peer, c->comm, c->stream));
+    NCCLCHK(ncclRecv(bs.w + (bs.ldv + rg.offset) * bs.es, (size_t)rg.count * bs.es, ncclDouble, rg.peer, c->comm, c->stream));
   NCCLCHK(ncclGroupEnd());
   return 0;
 }
@@ -311,7 +317,7 @@ int finish_send(eigenex_context_s* c, CsrShard& s, const std::vector<int32_t>& i
   s.nsend = (int64_t)idx_host.size();
   if (s.nsend == 0) return 0;
   HIPCHK(hipMalloc(&s.send_idx, sizeof(int32_t) * s.nsend));
-  HIPCHK(hipMalloc(&s.sendbuf, sizeof(double) * s.nsend));
+  HIPCHK(hipMalloc(&s.sendbuf, sizeof(double) * s.nsend * s.es));
   HIPCHK(hipMemcpyAsync(s.send_idx, idx_host.data(), sizeof(int32_t) * s.nsend, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
@@ -319,8 +325,9 @@ int finish_send(eigenex_context_s* c, CsrShard& s, const std::vector<int32_t>& i
 
 // Host-side shard construction from user CSR arrays (global columns).
 int build_shard_host(eigenex_context_s* c, int64_t n_global, int gshard, const int32_t* rowptr, const int32_t* col,
-                     const double* val, CsrShard& s) {
+                     const double* val, int es, CsrShard& s) {
   s.gshard = gshard;
+  s.es = es;
   partition(n_global, c->P, gshard, &s.rb, &s.re);
   s.nloc = s.re - s.rb;
   s.npad = pad_rows(s.nloc);
@@ -351,11 +358,11 @@ int build_shard_host(eigenex_context_s* c, int64_t n_global, int gshard, const i
   for (int64_t i = 0; i <= s.nloc; ++i) lrp[i] = (int32_t)(rowptr[i] - p0);
   HIPCHK(hipMalloc(&s.rowptr, sizeof(int32_t) * (s.nloc + 1)));
   HIPCHK(hipMalloc(&s.col, sizeof(int32_t) * (s.nnz + 8)));
-  HIPCHK(hipMalloc(&s.val, sizeof(double) * (s.nnz + 8)));
-  HIPCHK(hipMemsetAsync(s.val, 0, sizeof(double) * (s.nnz + 8), c->stream));
+  HIPCHK(hipMalloc(&s.val, sizeof(double) * (s.nnz + 8) * es));
+  HIPCHK(hipMemsetAsync(s.val, 0, sizeof(double) * (s.nnz + 8) * es, c->stream));
   HIPCHK(hipMemcpyAsync(s.rowptr, lrp.data(), sizeof(int32_t) * (s.nloc + 1), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(s.col, lcol.data(), sizeof(int32_t) * (s.nnz + 8), hipMemcpyHostToDevice, c->stream));
-  if (s.nnz) HIPCHK(hipMemcpyAsync(s.val, val + p0, sizeof(double) * s.nnz, hipMemcpyHostToDevice, c->stream));
+  if (s.nnz) HIPCHK(hipMemcpyAsync(s.val, val + p0 * es, sizeof(double) * s.nnz * es, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   build_recv(s, n_global, c->P);
   return 0;
@@ -427,24 +434,24 @@ int build_send_lists_loopback(eigenex_context_s* c, eigenex_csr_s* m) {
 }
 
 double* vec_ptr(BasisShard& s, int cap, int nq, int ref) {
-  if (ref >= 0) return ref < cap ? s.V + (int64_t)ref * s.ldv : nullptr;
+  if (ref >= 0) return ref < cap ? s.V + (int64_t)ref * s.ldd : nullptr;
   if (ref == EIGENEX_VEC_V) return s.v;
   if (ref == EIGENEX_VEC_W) return s.w;
   if (ref == EIGENEX_VEC_START) return s.start;
   const int q = -16 - ref;
-  if (q >= 0 && q < nq) return s.Q + (int64_t)q * s.ldv;
+  if (q >= 0 && q < nq) return s.Q + (int64_t)q * s.ldd;
   return nullptr;
 }
 
 ColumnSet colset(BasisShard& s, int first, int stride, int count, int qfirst, int nq) {
   ColumnSet cs;
   cs.V = s.V;
-  cs.ldv = s.ldv;
+  cs.ldv = s.ldd;
   cs.first = first;
   cs.stride = stride;
   cs.count = count;
-  cs.Q = s.Q ? s.Q + (int64_t)qfirst * s.ldv : nullptr;
-  cs.ldq = s.ldv;
+  cs.Q = s.Q ? s.Q + (int64_t)qfirst * s.ldd : nullptr;
+  cs.ldq = s.ldd;
   cs.nq = nq;
   return cs;
 }
@@ -458,17 +465,17 @@ int enq_dots(eigenex_basis_s* b, int src_ref, bool three_term, int k, int first,
   if (ncols <= 0) return 0;
   for (auto& s : b->sh) {
     ThreeTerm tt{nullptr, nullptr, nullptr, nullptr};
-    if (three_term) tt = ThreeTerm{s.V + (int64_t)k * s.ldv, k > 0 ? s.V + (int64_t)(k - 1) * s.ldv : nullptr, s.alpha + k, s.beta + (k > 0 ? k - 1 : 0)};
+    if (three_term) tt = ThreeTerm{s.V + (int64_t)k * s.ldd, k > 0 ? s.V + (int64_t)(k - 1) * s.ldd : nullptr, s.alpha + k, s.beta + (k > 0 ? k - 1 : 0)};
     const Ctrl* ctl = use_ctrl ? s.ctrl : s.ctrl_zero;
     {
-      ProfScope ps(c, EIGENEX_K_DOTS, 8.0 * s.nloc * ncols + 8.0 * s.nloc);
-      launch_dots(c->stream, vec_ptr(s, b->cap, b->nq, src_ref), tt, colset(s, first, stride, count, qfirst, nq), s.nloc,
-                  s.partials, s.pstride, s.g_vec, ctl);
+      ProfScope ps(c, EIGENEX_K_DOTS, 8.0 * s.nd * ncols + 8.0 * s.nd);
+      launch_dots(c->stream, vec_ptr(s, b->cap, b->nq, src_ref), tt, colset(s, first, stride, count, qfirst, nq), s.nd,
+                  s.partials, s.pstride, s.g_vec, ctl, b->es == 2);
     }
     ProfScope ps(c, EIGENEX_K_SMALL, 0.0);
-    launch_reduce(c->stream, s.partials, s.pstride, s.g_vec, ncols, s.hbuf + slot, ctl);
+    launch_reduce(c->stream, s.partials, s.pstride, s.g_vec, ncols * b->es, s.hbuf + slot * b->es, ctl);
   }
-  return allreduce(b, slot, ncols);
+  return allreduce(b, slot * b->es, ncols * b->es);
 }
 
 // dst = w0(src, tt) - sum h[slot+c]*col_c ; hbuf[slot_nrm] = all-reduced ||dst||^2 (if want_norm)
@@ -478,12 +485,13 @@ int enq_update(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_term, in
   const int ncols = count + nq;
   for (auto& s : b->sh) {
     ThreeTerm tt{nullptr, nullptr, nullptr, nullptr};
-    if (three_term) tt = ThreeTerm{s.V + (int64_t)k * s.ldv, k > 0 ? s.V + (int64_t)(k - 1) * s.ldv : nullptr, s.alpha + k, s.beta + (k > 0 ? k - 1 : 0)};
+    if (three_term) tt = ThreeTerm{s.V + (int64_t)k * s.ldd, k > 0 ? s.V + (int64_t)(k - 1) * s.ldd : nullptr, s.alpha + k, s.beta + (k > 0 ? k - 1 : 0)};
     const Ctrl* ctl = use_ctrl ? s.ctrl : s.ctrl_zero;
     {
-      ProfScope ps(c, EIGENEX_K_UPDATE, 8.0 * s.nloc * ncols + 24.0 * s.nloc + (three_term ? 32.0 * s.nloc : 0.0));
+      ProfScope ps(c, EIGENEX_K_UPDATE, 8.0 * s.nd * ncols + 24.0 * s.nd + (three_term ? 32.0 * s.nd : 0.0));
       launch_update(c->stream, vec_ptr(s, b->cap, b->nq, src_ref), vec_ptr(s, b->cap, b->nq, dst_ref), tt,
-                    colset(s, first, stride, count, qfirst, nq), s.hbuf + slot, s.nloc, s.partials, s.g_vec, ctl);
+                    colset(s, first, stride, count, qfirst, nq), s.hbuf + slot * b->es, s.nd, s.partials, s.g_vec, ctl,
+                    b->es == 2);
     }
     if (want_norm) {
       ProfScope ps(c, EIGENEX_K_SMALL, 0.0);
@@ -537,31 +545,38 @@ int enq_apply(eigenex_basis_s* b, int ucol, bool want_dot) {
     for (auto& s : b->sh) {
       CsrShard* m = s.csr;
       {
-        ProfScope ps(c, EIGENEX_K_SPMV, 12.0 * m->nnz + 4.0 * (m->nloc + 1) + 32.0 * m->nloc + (want_dot ? 16.0 * m->nloc : 0.0));
-        launch_spmv(c->stream, m->rowptr, m->col, m->val, s.w, &s.ctrl->scale, b->shift, s.v,
-                    s.V + (int64_t)ucol * s.ldv, s.nloc, want_dot ? s.partials : nullptr, s.g_spmv, s.ctrl);
+        ProfScope ps(c, EIGENEX_K_SPMV, (4.0 + 8.0 * b->es) * m->nnz + 4.0 * (m->nloc + 1) + 32.0 * s.nd + (want_dot ? 16.0 * s.nd : 0.0));
+        if (b->es == 2)
+          launch_spmv_z(c->stream, m->rowptr, m->col, m->val, s.w, &s.ctrl->scale, b->shift, b->shift_im, s.v,
+                        s.V + (int64_t)ucol * s.ldd, s.nloc, want_dot ? s.partials : nullptr, s.pstride, s.g_spmv, s.ctrl);
+        else
+          launch_spmv(c->stream, m->rowptr, m->col, m->val, s.w, &s.ctrl->scale, b->shift, s.v,
+                      s.V + (int64_t)ucol * s.ldd, s.nloc, want_dot ? s.partials : nullptr, s.g_spmv, s.ctrl);
       }
       if (want_dot) {
         ProfScope ps(c, EIGENEX_K_SMALL, 0.0);
-        launch_reduce(c->stream, s.partials, s.pstride, s.g_spmv, 1, s.hbuf + b->slot_alpha(), s.ctrl);
+        launch_reduce(c->stream, s.partials, s.pstride, s.g_spmv, b->es, s.hbuf + b->slot_alpha(), s.ctrl);
       }
     }
-    return want_dot ? allreduce(b, b->slot_alpha(), 1) : 0;
+    return want_dot ? allreduce(b, b->slot_alpha(), b->es) : 0;
   }
   // operator lives in host code (MatMulFunction, lanczos.hpp:116): stage through pinned memory
   if (!b->fn) return fail(EIGENEX_ERR_STATE, "no operator: neither a CSR handle nor a host callback is set");
   BasisShard& s = b->sh[0];
-  double* u = s.V + (int64_t)ucol * s.ldv;
-  launch_scale(c->stream, s.w, &s.ctrl->scale, 1.0, u, s.nloc, s.ctrl);
-  HIPCHK(hipMemcpyAsync(b->pin_in, u, sizeof(double) * s.nloc, hipMemcpyDeviceToHost, c->stream));
+  double* u = s.V + (int64_t)ucol * s.ldd;
+  launch_scale(c->stream, s.w, &s.ctrl->scale, 1.0, u, s.nd, s.ctrl);
+  HIPCHK(hipMemcpyAsync(b->pin_in, u, sizeof(double) * s.nd, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(b->pin_ctrl, s.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   if (b->pin_ctrl->stopped) return 0;  // the reference would not have called the operator
   b->fn(b->pin_in, b->pin_out, b->fn_user);
-  HIPCHK(hipMemcpyAsync(s.v, b->pin_out, sizeof(double) * s.nloc, hipMemcpyHostToDevice, c->stream));
-  if (want_dot || b->shift != 0.0) {
-    launch_shift_dot(c->stream, s.v, u, b->shift, s.nloc, s.partials, s.g_vec, s.ctrl);
-    launch_reduce(c->stream, s.partials, s.pstride, s.g_vec, 1, s.hbuf + b->slot_alpha(), s.ctrl);
+  HIPCHK(hipMemcpyAsync(s.v, b->pin_out, sizeof(double) * s.nd, hipMemcpyHostToDevice, c->stream));
+  if (want_dot || b->shift != 0.0 || b->shift_im != 0.0) {
+    if (b->es == 2)
+      launch_shift_dot_z(c->stream, s.v, u, b->shift, b->shift_im, s.nloc, s.partials, s.pstride, s.g_vec, s.ctrl);
+    else
+      launch_shift_dot(c->stream, s.v, u, b->shift, s.nloc, s.partials, s.g_vec, s.ctrl);
+    launch_reduce(c->stream, s.partials, s.pstride, s.g_vec, b->es, s.hbuf + b->slot_alpha(), s.ctrl);
   }
   return 0;
 }
@@ -617,7 +632,7 @@ int arnoldi_call(eigenex_basis_s* b) {
   } else {
     k = b->h_nvec;
     if (k >= b->cap && (int64_t)k < b->n_global) return fail(EIGENEX_ERR_STATE, "basis capacity exhausted");
-    for (auto& s : b->sh) launch_arnoldi_begin(st, s.ctrl, b->threshold, b->n_global, b->cap, s.H, b->ldh);  // :357-365
+    for (auto& s : b->sh) launch_arnoldi_begin(st, s.ctrl, b->threshold, b->n_global, b->cap, s.H, b->ldh, b->es);  // :357-365
     if (k >= b->cap) return 0;  // full Krylov space: the begin kernel has recorded "returned false"
   }
   CHK(enq_apply(b, k, false));  // :333-336, :369-372
@@ -626,7 +641,7 @@ int arnoldi_call(eigenex_basis_s* b) {
   CHK(enq_orthogonalize(b, EIGENEX_VEC_V, EIGENEX_VEC_W, false, 0, 0, 1, k + 1, b->nq, true));
   for (auto& s : b->sh) {
     launch_fin_norm(st, s.ctrl, s.hbuf + b->slot_nrm(), b->threshold, kFinArnoldi, s.beta);  // :348, :385
-    launch_arnoldi_end(st, s.ctrl, s.hbuf, s.H, b->ldh);
+    launch_arnoldi_end(st, s.ctrl, s.hbuf, s.H, b->ldh, b->es);
   }
   b->h_nvec = k + 1;
   return 0;
@@ -866,8 +881,8 @@ int eigenex_profile_get(eigenex_context_t c, int kind, int64_t* launches, double
 }
 
 // ---- operator ---------------------------------------------------------------
-int eigenex_csr_upload(eigenex_context_t c, int64_t n_global, int64_t row_begin, int64_t n_rows, const int32_t* rowptr,
-                       const int32_t* col_global, const double* val, eigenex_csr_t* out) {
+static int csr_upload_impl(eigenex_context_t c, int64_t n_global, int64_t row_begin, int64_t n_rows, const int32_t* rowptr,
+                           const int32_t* col_global, const double* val, int es, eigenex_csr_t* out) {
   if (!c || !out || !rowptr || n_global <= 0 || n_rows < 0) return fail(EIGENEX_ERR_ARG, "eigenex_csr_upload: bad argument");
   if (n_rows > 0 && rowptr[n_rows] > rowptr[0] && (!col_global || !val)) return fail(EIGENEX_ERR_ARG, "col/val is NULL");
   HIPCHK(hipSetDevice(c->device));
@@ -879,12 +894,13 @@ int eigenex_csr_upload(eigenex_context_t c, int64_t n_global, int64_t row_begin,
   auto* m = new eigenex_csr_s();
   m->ctx = c;
   m->n_global = n_global;
+  m->es = es;
   m->sh.resize(c->local.size());
   int rc = 0;
   for (size_t i = 0; i < c->local.size() && !rc; ++i) {
     int64_t rb, re;
     partition(n_global, c->P, c->local[i], &rb, &re);
-    rc = build_shard_host(c, n_global, c->local[i], rowptr + (rb - row_begin), col_global, val, m->sh[i]);
+    rc = build_shard_host(c, n_global, c->local[i], rowptr + (rb - row_begin), col_global, val, es, m->sh[i]);
   }
   if (!rc && c->P > 1) rc = c->loopback ? build_send_lists_loopback(c, m) : exchange_send_lists_rccl(c, n_global, m->sh[0]);
   if (rc) {
@@ -895,6 +911,16 @@ int eigenex_csr_upload(eigenex_context_t c, int64_t n_global, int64_t row_begin,
   }
   *out = m;
   return 0;
+}
+
+int eigenex_csr_upload(eigenex_context_t c, int64_t n_global, int64_t row_begin, int64_t n_rows, const int32_t* rowptr,
+                       const int32_t* col_global, const double* val, eigenex_csr_t* out) {
+  return csr_upload_impl(c, n_global, row_begin, n_rows, rowptr, col_global, val, 1, out);
+}
+
+int eigenex_csr_upload_z(eigenex_context_t c, int64_t n_global, int64_t row_begin, int64_t n_rows, const int32_t* rowptr,
+                         const int32_t* col_global, const double* val_interleaved, eigenex_csr_t* out) {
+  return csr_upload_impl(c, n_global, row_begin, n_rows, rowptr, col_global, val_interleaved, 2, out);
 }
 
 int eigenex_csr_laplacian3d(eigenex_context_t c, int64_t n, eigenex_csr_t* out) {
@@ -1017,7 +1043,19 @@ int eigenex_basis_destroy(eigenex_basis_t b) {
 
 int eigenex_basis_create(eigenex_context_t c, eigenex_csr_t csr, int64_t n_global, int capacity, int n_ortho,
                          eigenex_basis_t* out) {
+  return eigenex_basis_create_ex(c, csr, n_global, capacity, n_ortho, csr ? (csr->es == 2) : 0, out);
+}
+
+int eigenex_basis_is_complex(eigenex_basis_t b, int* is_complex) {
+  if (!b || !is_complex) return fail(EIGENEX_ERR_ARG, "NULL argument");
+  *is_complex = b->es == 2;
+  return 0;
+}
+
+int eigenex_basis_create_ex(eigenex_context_t c, eigenex_csr_t csr, int64_t n_global, int capacity, int n_ortho,
+                            int is_complex, eigenex_basis_t* out) {
   if (!c || !out || n_global <= 0 || capacity < 1 || n_ortho < 0) return fail(EIGENEX_ERR_ARG, "eigenex_basis_create: bad argument");
+  if (csr && (csr->es == 2) != (is_complex != 0)) return fail(EIGENEX_ERR_ARG, "scalar type of the basis and of the CSR operator differ");
   if (csr && (csr->ctx != c || csr->n_global != n_global)) return fail(EIGENEX_ERR_ARG, "csr belongs to another context or has another size");
   if (!csr && c->P != 1) return fail(EIGENEX_ERR_ARG, "a host-callback operator needs a single-shard context");
   HIPCHK(hipSetDevice(c->device));
@@ -1029,6 +1067,7 @@ int eigenex_basis_create(eigenex_context_t c, eigenex_csr_t csr, int64_t n_globa
   b->nq = n_ortho;
   b->maxcols = capacity + n_ortho;
   b->ldh = capacity + 2;
+  b->es = is_complex ? 2 : 1;
   b->sh.resize(c->local.size());
   auto body = [&]() -> int {
     for (size_t i = 0; i < c->local.size(); ++i) {
@@ -1042,7 +1081,10 @@ int eigenex_basis_create(eigenex_context_t c, eigenex_csr_t csr, int64_t n_globa
       if (s.ldv == 0) s.ldv = 64;
       s.csr = csr ? &csr->sh[i] : nullptr;
       s.nhalo = s.csr ? s.csr->nhalo : 0;
-      const size_t vbytes = sizeof(double) * (size_t)s.ldv;
+      s.es = b->es;
+      s.nd = s.nloc * s.es;
+      s.ldd = s.ldv * s.es;
+      const size_t vbytes = sizeof(double) * (size_t)s.ldd;
       HIPCHK(hipMalloc(&s.V, vbytes * capacity));
       HIPCHK(hipMemsetAsync(s.V, 0, vbytes * capacity, c->stream));
       if (n_ortho) {
@@ -1053,21 +1095,21 @@ int eigenex_basis_create(eigenex_context_t c, eigenex_csr_t csr, int64_t n_globa
       HIPCHK(hipMemsetAsync(s.v, 0, vbytes, c->stream));
       HIPCHK(hipMalloc(&s.start, vbytes));
       HIPCHK(hipMemsetAsync(s.start, 0, vbytes, c->stream));
-      HIPCHK(hipMalloc(&s.w, sizeof(double) * (size_t)(s.ldv + s.nhalo + 8)));
-      HIPCHK(hipMemsetAsync(s.w, 0, sizeof(double) * (size_t)(s.ldv + s.nhalo + 8), c->stream));
-      s.g_vec = grid_for_tiles((s.nloc + kTileRows - 1) / kTileRows, 4);
+      HIPCHK(hipMalloc(&s.w, sizeof(double) * (size_t)(s.ldv + s.nhalo + 8) * s.es));
+      HIPCHK(hipMemsetAsync(s.w, 0, sizeof(double) * (size_t)(s.ldv + s.nhalo + 8) * s.es, c->stream));
+      s.g_vec = grid_for_tiles((s.nd + kTileRows - 1) / kTileRows, 4);
       s.g_spmv = grid_for_tiles((s.nloc + kSpmvRows - 1) / kSpmvRows, 8);
       s.pstride = std::max(s.g_vec, s.g_spmv);
-      const int rows = std::max(b->maxcols, 8) + 4;
+      const int rows = 2 * std::max(b->maxcols, 8) + 4;
       HIPCHK(hipMalloc(&s.partials, sizeof(double) * (size_t)s.pstride * rows));
-      HIPCHK(hipMalloc(&s.hbuf, sizeof(double) * (b->maxcols + 40)));
-      HIPCHK(hipMemsetAsync(s.hbuf, 0, sizeof(double) * (b->maxcols + 40), c->stream));
+      HIPCHK(hipMalloc(&s.hbuf, sizeof(double) * (2 * b->maxcols + 40)));
+      HIPCHK(hipMemsetAsync(s.hbuf, 0, sizeof(double) * (2 * b->maxcols + 40), c->stream));
       HIPCHK(hipMalloc(&s.alpha, sizeof(double) * (capacity + 2)));
       HIPCHK(hipMalloc(&s.beta, sizeof(double) * (capacity + 2)));
       HIPCHK(hipMemsetAsync(s.alpha, 0, sizeof(double) * (capacity + 2), c->stream));
       HIPCHK(hipMemsetAsync(s.beta, 0, sizeof(double) * (capacity + 2), c->stream));
-      HIPCHK(hipMalloc(&s.H, sizeof(double) * (size_t)b->ldh * (capacity + 1)));
-      HIPCHK(hipMemsetAsync(s.H, 0, sizeof(double) * (size_t)b->ldh * (capacity + 1), c->stream));
+      HIPCHK(hipMalloc(&s.H, sizeof(double) * (size_t)b->ldh * (capacity + 1) * s.es));
+      HIPCHK(hipMemsetAsync(s.H, 0, sizeof(double) * (size_t)b->ldh * (capacity + 1) * s.es, c->stream));
       HIPCHK(hipMalloc(&s.ctrl, sizeof(Ctrl)));
       HIPCHK(hipMalloc(&s.ctrl_zero, sizeof(Ctrl)));
       HIPCHK(hipMemsetAsync(s.ctrl, 0, sizeof(Ctrl), c->stream));
@@ -1075,8 +1117,8 @@ int eigenex_basis_create(eigenex_context_t c, eigenex_csr_t csr, int64_t n_globa
     }
     HIPCHK(hipHostMalloc(&b->pin_ctrl, sizeof(Ctrl)));
     if (!csr) {
-      HIPCHK(hipHostMalloc(&b->pin_in, sizeof(double) * (size_t)b->sh[0].ldv));
-      HIPCHK(hipHostMalloc(&b->pin_out, sizeof(double) * (size_t)b->sh[0].ldv));
+      HIPCHK(hipHostMalloc(&b->pin_in, sizeof(double) * (size_t)b->sh[0].ldd));
+      HIPCHK(hipHostMalloc(&b->pin_out, sizeof(double) * (size_t)b->sh[0].ldd));
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
@@ -1106,25 +1148,25 @@ int eigenex_basis_reserve(eigenex_basis_t b, int capacity) {
   const int oldcap = b->cap, oldldh = b->ldh;
   const int newmax = capacity + b->nq, newldh = capacity + 2;
   for (auto& s : b->sh) {
-    const size_t vbytes = sizeof(double) * (size_t)s.ldv;
+    const size_t vbytes = sizeof(double) * (size_t)s.ldd;
     double *V = nullptr, *partials = nullptr, *hbuf = nullptr, *alpha = nullptr, *beta = nullptr, *H = nullptr;
     HIPCHK(hipMalloc(&V, vbytes * capacity));
     HIPCHK(hipMemcpyAsync(V, s.V, vbytes * oldcap, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(hipMemsetAsync(V + (size_t)s.ldv * oldcap, 0, vbytes * (capacity - oldcap), c->stream));
-    const int rows = std::max(newmax, 8) + 4;
+    HIPCHK(hipMemsetAsync(V + (size_t)s.ldd * oldcap, 0, vbytes * (capacity - oldcap), c->stream));
+    const int rows = 2 * std::max(newmax, 8) + 4;
     HIPCHK(hipMalloc(&partials, sizeof(double) * (size_t)s.pstride * rows));
-    HIPCHK(hipMalloc(&hbuf, sizeof(double) * (newmax + 40)));
-    HIPCHK(hipMemsetAsync(hbuf, 0, sizeof(double) * (newmax + 40), c->stream));
+    HIPCHK(hipMalloc(&hbuf, sizeof(double) * (2 * newmax + 40)));
+    HIPCHK(hipMemsetAsync(hbuf, 0, sizeof(double) * (2 * newmax + 40), c->stream));
     HIPCHK(hipMalloc(&alpha, sizeof(double) * (capacity + 2)));
     HIPCHK(hipMalloc(&beta, sizeof(double) * (capacity + 2)));
     HIPCHK(hipMemsetAsync(alpha, 0, sizeof(double) * (capacity + 2), c->stream));
     HIPCHK(hipMemsetAsync(beta, 0, sizeof(double) * (capacity + 2), c->stream));
     HIPCHK(hipMemcpyAsync(alpha, s.alpha, sizeof(double) * (oldcap + 2), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(beta, s.beta, sizeof(double) * (oldcap + 2), hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(hipMalloc(&H, sizeof(double) * (size_t)newldh * (capacity + 1)));
-    HIPCHK(hipMemsetAsync(H, 0, sizeof(double) * (size_t)newldh * (capacity + 1), c->stream));
-    HIPCHK(hipMemcpy2DAsync(H, sizeof(double) * newldh, s.H, sizeof(double) * oldldh, sizeof(double) * oldldh, oldcap + 1,
-                            hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMalloc(&H, sizeof(double) * (size_t)newldh * (capacity + 1) * s.es));
+    HIPCHK(hipMemsetAsync(H, 0, sizeof(double) * (size_t)newldh * (capacity + 1) * s.es, c->stream));
+    HIPCHK(hipMemcpy2DAsync(H, sizeof(double) * newldh * s.es, s.H, sizeof(double) * oldldh * s.es, sizeof(double) * oldldh * s.es,
+                            oldcap + 1, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     for (void* p : {(void*)s.V, (void*)s.partials, (void*)s.hbuf, (void*)s.alpha, (void*)s.beta, (void*)s.H}) (void)hipFree(p);
     s.V = V, s.partials = partials, s.hbuf = hbuf, s.alpha = alpha, s.beta = beta, s.H = H;
@@ -1144,9 +1186,16 @@ int eigenex_basis_set_host_operator(eigenex_basis_t b, eigenex_matvec_fn fn, voi
 }
 
 int eigenex_basis_configure(eigenex_basis_t b, double eigenvalue_shift, double threshold, int64_t interval, int ortho_mode) {
+  return eigenex_basis_configure_z(b, eigenvalue_shift, 0.0, threshold, interval, ortho_mode);
+}
+
+int eigenex_basis_configure_z(eigenex_basis_t b, double shift_re, double shift_im, double threshold, int64_t interval,
+                              int ortho_mode) {
   if (!b) return fail(EIGENEX_ERR_ARG, "basis is NULL");
   if (ortho_mode != EIGENEX_ORTHO_BATCHED && ortho_mode != EIGENEX_ORTHO_SEQUENTIAL) return fail(EIGENEX_ERR_ARG, "bad ortho_mode");
-  b->shift = eigenvalue_shift;
+  if (shift_im != 0.0 && b->es != 2) return fail(EIGENEX_ERR_ARG, "a complex shift needs a complex basis");
+  b->shift = shift_re;
+  b->shift_im = shift_im;
   b->threshold = threshold;
   b->interval = interval;
   b->ortho_mode = ortho_mode;
@@ -1171,9 +1220,9 @@ static int vec_copy(eigenex_basis_t b, int ref, double* host, bool up) {
     double* d = vec_ptr(s, b->cap, b->nq, ref);
     if (!d) return fail(EIGENEX_ERR_ARG, "bad vector reference");
     if (up)
-      HIPCHK(hipMemcpyAsync(d, host + (s.rb - rb0), sizeof(double) * s.nloc, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(hipMemcpyAsync(d, host + (s.rb - rb0) * s.es, sizeof(double) * s.nd, hipMemcpyHostToDevice, c->stream));
     else
-      HIPCHK(hipMemcpyAsync(host + (s.rb - rb0), d, sizeof(double) * s.nloc, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipMemcpyAsync(host + (s.rb - rb0) * s.es, d, sizeof(double) * s.nd, hipMemcpyDeviceToHost, c->stream));
   }
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
@@ -1189,7 +1238,7 @@ int eigenex_vec_copy(eigenex_basis_t b, int dst_ref, int src_ref) {
   for (auto& s : b->sh) {
     double *d = vec_ptr(s, b->cap, b->nq, dst_ref), *x = vec_ptr(s, b->cap, b->nq, src_ref);
     if (!d || !x) return fail(EIGENEX_ERR_ARG, "bad vector reference");
-    if (d != x) HIPCHK(hipMemcpyAsync(d, x, sizeof(double) * s.nloc, hipMemcpyDeviceToDevice, c->stream));
+    if (d != x) HIPCHK(hipMemcpyAsync(d, x, sizeof(double) * s.nd, hipMemcpyDeviceToDevice, c->stream));
   }
   return 0;
 }
@@ -1224,19 +1273,23 @@ int eigenex_apply(eigenex_basis_t b, int x_ref, int y_ref, double shift, double*
     double* x = vec_ptr(s, b->cap, b->nq, x_ref);
     double* y = vec_ptr(s, b->cap, b->nq, y_ref);
     if (!x || !y || x == y) return fail(EIGENEX_ERR_ARG, "bad vector reference");
-    if (x != s.w) HIPCHK(hipMemcpyAsync(s.w, x, sizeof(double) * s.nloc, hipMemcpyDeviceToDevice, c->stream));
+    if (x != s.w) HIPCHK(hipMemcpyAsync(s.w, x, sizeof(double) * s.nd, hipMemcpyDeviceToDevice, c->stream));
   }
   CHK(halo_exchange(b, false));
   for (auto& s : b->sh) {
     CsrShard* m = s.csr;
-    ProfScope ps(c, EIGENEX_K_SPMV, 12.0 * m->nnz + 4.0 * (m->nloc + 1) + 16.0 * m->nloc);
-    launch_spmv(c->stream, m->rowptr, m->col, m->val, s.w, nullptr, shift, vec_ptr(s, b->cap, b->nq, y_ref), nullptr,
-                s.nloc, dot ? s.partials : nullptr, s.g_spmv, s.ctrl_zero);
-    if (dot) launch_reduce(c->stream, s.partials, s.pstride, s.g_spmv, 1, s.hbuf + b->slot_alpha(), s.ctrl_zero);
+    ProfScope ps(c, EIGENEX_K_SPMV, (4.0 + 8.0 * b->es) * m->nnz + 4.0 * (m->nloc + 1) + 16.0 * s.nd);
+    if (b->es == 2)
+      launch_spmv_z(c->stream, m->rowptr, m->col, m->val, s.w, nullptr, shift, 0.0, vec_ptr(s, b->cap, b->nq, y_ref), nullptr,
+                    s.nloc, dot ? s.partials : nullptr, s.pstride, s.g_spmv, s.ctrl_zero);
+    else
+      launch_spmv(c->stream, m->rowptr, m->col, m->val, s.w, nullptr, shift, vec_ptr(s, b->cap, b->nq, y_ref), nullptr,
+                  s.nloc, dot ? s.partials : nullptr, s.g_spmv, s.ctrl_zero);
+    if (dot) launch_reduce(c->stream, s.partials, s.pstride, s.g_spmv, b->es, s.hbuf + b->slot_alpha(), s.ctrl_zero);
   }
   if (dot) {
-    CHK(allreduce(b, b->slot_alpha(), 1));
-    return fetch_h(b, b->slot_alpha(), 1, dot);
+    CHK(allreduce(b, b->slot_alpha(), b->es));
+    return fetch_h(b, b->slot_alpha(), b->es, dot);
   }
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
@@ -1248,7 +1301,7 @@ int eigenex_dots(eigenex_basis_t b, int w_ref, int first, int stride, int count,
   if (!vec_ptr(b->sh[0], b->cap, b->nq, w_ref)) return fail(EIGENEX_ERR_ARG, "bad vector reference");
   HIPCHK(hipSetDevice(b->ctx->device));
   CHK(enq_dots(b, w_ref, false, 0, first, stride, count, 0, n_ortho_used, 0, false));
-  return fetch_h(b, 0, count + n_ortho_used, h);
+  return fetch_h(b, 0, (count + n_ortho_used) * b->es, h);
 }
 
 int eigenex_update(eigenex_basis_t b, int w_ref, int first, int stride, int count, int n_ortho_used, const double* h,
@@ -1258,7 +1311,7 @@ int eigenex_update(eigenex_basis_t b, int w_ref, int first, int stride, int coun
   if (count + n_ortho_used > 0 && !h) return fail(EIGENEX_ERR_ARG, "h is NULL");
   if (!vec_ptr(b->sh[0], b->cap, b->nq, w_ref)) return fail(EIGENEX_ERR_ARG, "bad vector reference");
   HIPCHK(hipSetDevice(b->ctx->device));
-  if (count + n_ortho_used > 0) CHK(push_h(b, 0, count + n_ortho_used, h));
+  if (count + n_ortho_used > 0) CHK(push_h(b, 0, (count + n_ortho_used) * b->es, h));
   CHK(enq_update(b, w_ref, w_ref, false, 0, first, stride, count, 0, n_ortho_used, 0, true, false));
   if (nrm2) return fetch_h(b, b->slot_nrm(), 1, nrm2);
   HIPCHK(hipStreamSynchronize(b->ctx->stream));
@@ -1276,8 +1329,8 @@ int eigenex_axpy2(eigenex_basis_t b, int z_ref, int x_ref, double a, int p_ref, 
     double *p = vec_ptr(s, b->cap, b->nq, p_ref), *q = vec_ptr(s, b->cap, b->nq, q_ref);
     if (!z || !x || !p || !q) return fail(EIGENEX_ERR_ARG, "bad vector reference");
     ThreeTerm tt{p, bcoef != 0.0 ? q : nullptr, s.hbuf + b->slot_a(), s.hbuf + b->slot_b()};
-    ProfScope ps(c, EIGENEX_K_UPDATE, 32.0 * s.nloc);
-    launch_update(c->stream, x, z, tt, colset(s, 0, 1, 0, 0, 0), s.hbuf, s.nloc, s.partials, s.g_vec, s.ctrl_zero);
+    ProfScope ps(c, EIGENEX_K_UPDATE, 32.0 * s.nd);
+    launch_update(c->stream, x, z, tt, colset(s, 0, 1, 0, 0, 0), s.hbuf, s.nd, s.partials, s.g_vec, s.ctrl_zero, b->es == 2);
   }
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
@@ -1290,7 +1343,7 @@ int eigenex_scale(eigenex_basis_t b, int dst_ref, int src_ref, double sc) {
   for (auto& s : b->sh) {
     double *d = vec_ptr(s, b->cap, b->nq, dst_ref), *x = vec_ptr(s, b->cap, b->nq, src_ref);
     if (!d || !x) return fail(EIGENEX_ERR_ARG, "bad vector reference");
-    launch_scale(c->stream, x, nullptr, sc, d, s.nloc, s.ctrl_zero);
+    launch_scale(c->stream, x, nullptr, sc, d, s.nd, s.ctrl_zero);
   }
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
@@ -1332,8 +1385,9 @@ int eigenex_arnoldi_state(eigenex_basis_t b, eigenex_state_t* st, double* hess, 
   fill_state(ct, st);
   if (hess && ct.nalpha) {
     if (ldh < ct.nalpha + 1) return fail(EIGENEX_ERR_ARG, "ldh too small");
-    HIPCHK(hipMemcpy2DAsync(hess, sizeof(double) * ldh, b->sh[0].H, sizeof(double) * b->ldh, sizeof(double) * (ct.nalpha + 1),
-                            ct.nalpha, hipMemcpyDeviceToHost, b->ctx->stream));
+    const int es = b->es;  // complex: (re, im) pairs, hess has 2*ldh doubles per column
+    HIPCHK(hipMemcpy2DAsync(hess, sizeof(double) * ldh * es, b->sh[0].H, sizeof(double) * b->ldh * es,
+                            sizeof(double) * (ct.nalpha + 1) * es, ct.nalpha, hipMemcpyDeviceToHost, b->ctx->stream));
     HIPCHK(hipStreamSynchronize(b->ctx->stream));
   }
   return 0;
@@ -1344,52 +1398,74 @@ int eigenex_arnoldi_state(eigenex_basis_t b, eigenex_state_t* st, double* hess, 
 // ---- Ritz vectors -----------------------------------------------------------------------
 namespace {
 
-// One pass over the basis for up to 8 real coefficient columns: s.X[:, e] = V * cols[e] on
-// every shard; returns the all-reduced squared norms and, per column, the value of the first
-// non-zero entry in global row order together with its global row (n_global if none).
-int ritz_chunk(eigenex_basis_s* b, int nvec, int ne, const double* const* cols, double* d_S, double* nrm2,
-               double* first_row, double* first_val) {
+// One pass over the basis for up to 8 REAL coefficient columns: s.X[:, e] = V * cols[e] on every
+// shard (a complex basis is treated as 2N interleaved doubles: real coefficients act on both
+// parts alike).  hbuf[0..ne) receives the all-reduced squared norms of the raw columns.
+int ritz_raw(eigenex_basis_s* b, int nvec, int ne, const double* const* cols, double* d_S) {
   eigenex_context_s* c = b->ctx;
-  const int E = 8;
   for (int e = 0; e < ne; ++e)
     HIPCHK(hipMemcpyAsync(d_S + (size_t)e * nvec, cols[e], sizeof(double) * nvec, hipMemcpyHostToDevice, c->stream));
   for (auto& s : b->sh) {
     {
-      ProfScope ps(c, EIGENEX_K_RITZ, 8.0 * s.nloc * nvec + 8.0 * s.nloc * ne);
-      launch_ritz(c->stream, s.V, s.ldv, nvec, d_S, nvec, ne, s.X, s.ldv, s.nloc, s.partials, s.pstride, s.g_vec);
+      ProfScope ps(c, EIGENEX_K_RITZ, 8.0 * s.nd * nvec + 8.0 * s.nd * ne);
+      launch_ritz(c->stream, s.V, s.ldd, nvec, d_S, nvec, ne, s.X, s.ldd, s.nd, s.partials, s.pstride, s.g_vec);
     }
     launch_reduce(c->stream, s.partials, s.pstride, s.g_vec, ne, s.hbuf, s.ctrl_zero);
   }
-  CHK(allreduce(b, 0, ne));  // hbuf[0..ne) = ||x_e||^2
-  for (auto& s : b->sh) launch_first_nonzero(c->stream, s.X, s.ldv, ne, s.nloc, s.hbuf + E);
-  std::vector<double> idxval((size_t)2 * E * c->P, 0.0);
+  return allreduce(b, 0, ne);
+}
+
+// Finishes `ncol` columns held in bufs[shard] (column e at + e*ld_doubles, oes doubles per entry):
+// each column is divided by its norm (nrm2[e], all-reduced) and by the phase z/|z| of its first
+// entry with |z| > 0 in global row order (lanczos.hpp:806-816, arnoldi.hpp:854-865), then copied
+// to the host (rows owned by this context; host column stride ldx entries).
+int ritz_finish(eigenex_basis_s* b, const std::vector<double*>& bufs, const std::vector<int64_t>& ld_doubles, int oes,
+                int ncol, const double* nrm2, double* X, int64_t ldx, int col0) {
+  eigenex_context_s* c = b->ctx;
+  const int E = 8;
+  for (size_t i = 0; i < b->sh.size(); ++i)
+    launch_first_nonzero(c->stream, bufs[i], ld_doubles[i], ncol, b->sh[i].nloc, oes, b->sh[i].hbuf + E);
+  std::vector<double> first((size_t)3 * E * c->P, 0.0);
   if (c->loopback || c->P == 1) {
     for (size_t i = 0; i < b->sh.size(); ++i)
-      HIPCHK(hipMemcpyAsync(idxval.data() + 2 * E * i, b->sh[i].hbuf + E, sizeof(double) * 2 * ne, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipMemcpyAsync(first.data() + 3 * E * i, b->sh[i].hbuf + E, sizeof(double) * 3 * ncol, hipMemcpyDeviceToHost, c->stream));
   } else {
     double* tmp = nullptr;
-    HIPCHK(hipMalloc(&tmp, sizeof(double) * 2 * E * c->P));
-    NCCLCHK(ncclAllGather(b->sh[0].hbuf + E, tmp, (size_t)2 * E, ncclDouble, c->comm, c->stream));
-    HIPCHK(hipMemcpyAsync(idxval.data(), tmp, sizeof(double) * 2 * E * c->P, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMalloc(&tmp, sizeof(double) * 3 * E * c->P));
+    NCCLCHK(ncclAllGather(b->sh[0].hbuf + E, tmp, (size_t)3 * E, ncclDouble, c->comm, c->stream));
+    HIPCHK(hipMemcpyAsync(first.data(), tmp, sizeof(double) * 3 * E * c->P, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     (void)hipFree(tmp);
   }
-  HIPCHK(hipMemcpyAsync(nrm2, b->sh[0].hbuf, sizeof(double) * ne, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  for (int e = 0; e < ne; ++e) {
-    first_row[e] = (double)b->n_global;
-    first_val[e] = 0.0;
+  double factors[2 * E];
+  for (int e = 0; e < ncol; ++e) {
+    double pr = 1.0, pi = 0.0;
     for (int p = 0; p < c->P; ++p) {  // shards in row order: the first one with a hit wins
       int64_t pb, pe;
       partition(b->n_global, c->P, p, &pb, &pe);
-      const double idx = idxval[(size_t)2 * E * p + 2 * e];
-      if (idx < (double)(pe - pb)) {
-        first_row[e] = (double)pb + idx;
-        first_val[e] = idxval[(size_t)2 * E * p + 2 * e + 1];
+      const double* f = first.data() + (size_t)3 * E * p + 3 * e;
+      if (f[0] < (double)(pe - pb)) {
+        const double az = std::hypot(f[1], f[2]);
+        pr = f[1] / az;  // phase_factor = value / abs(value)
+        pi = f[2] / az;
         break;
       }
     }
+    const double nrm = std::sqrt(nrm2[e]);
+    const double inv = nrm > 0.0 ? 1.0 / nrm : 1.0;  // Eigen's normalized() leaves a zero vector alone
+    factors[2 * e] = pr * inv;       // (1/phase) * x/|x| = conj(phase) * x / |x|   (|phase| = 1)
+    factors[2 * e + 1] = -pi * inv;
   }
+  for (size_t i = 0; i < b->sh.size(); ++i) {
+    BasisShard& s = b->sh[i];
+    HIPCHK(hipMemcpyAsync(s.hbuf, factors, sizeof(double) * 2 * ncol, hipMemcpyHostToDevice, c->stream));
+    launch_scale_columns(c->stream, bufs[i], ld_doubles[i], ncol, s.nloc, oes, s.hbuf);
+    for (int e = 0; e < ncol; ++e)
+      HIPCHK(hipMemcpyAsync(X + ((size_t)(col0 + e) * ldx + (s.rb - b->sh[0].rb)) * oes, bufs[i] + (size_t)e * ld_doubles[i],
+                            sizeof(double) * s.nloc * oes, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
 
@@ -1397,7 +1473,7 @@ int ritz_chunk(eigenex_basis_s* b, int nvec, int ne, const double* const* cols, 
 
 extern "C" {
 
-// real coefficients (lanczos.hpp:798-816)
+// real coefficients (lanczos.hpp:798-816).  X has the basis' scalar type: real, or interleaved complex.
 int eigenex_ritz_vectors(eigenex_basis_t b, int nvec, int nev, const double* S, int lds, double* X, int64_t ldx) {
   if (!b || nvec < 0 || nvec > b->cap || nev < 0 || (nev && (!S || !X)) || lds < nvec) return fail(EIGENEX_ERR_ARG, "eigenex_ritz_vectors: bad argument");
   eigenex_context_s* c = b->ctx;
@@ -1409,26 +1485,22 @@ int eigenex_ritz_vectors(eigenex_basis_t b, int nvec, int nev, const double* S, 
   double* d_S = nullptr;
   HIPCHK(hipMalloc(&d_S, sizeof(double) * (size_t)std::max(nvec, 1) * E));
   int rc = [&]() -> int {
-    for (auto& s : b->sh)
-      if (!s.X) HIPCHK(hipMalloc(&s.X, sizeof(double) * (size_t)s.ldv * E));
+    std::vector<double*> bufs;
+    std::vector<int64_t> lds_;
+    for (auto& s : b->sh) {
+      if (!s.X) HIPCHK(hipMalloc(&s.X, sizeof(double) * (size_t)s.ldd * E));
+      bufs.push_back(s.X);
+      lds_.push_back(s.ldd);
+    }
     for (int e0 = 0; e0 < nev; e0 += E) {
       const int ne = std::min(E, nev - e0);
       const double* cols[E];
       for (int e = 0; e < ne; ++e) cols[e] = S + (size_t)(e0 + e) * lds;
-      double nrm2[E], frow[E], fval[E], factors[E];
-      CHK(ritz_chunk(b, nvec, ne, cols, d_S, nrm2, frow, fval));
-      for (int e = 0; e < ne; ++e) {
-        const double phase = fval[e] != 0.0 ? fval[e] / std::fabs(fval[e]) : 1.0;  // lanczos.hpp:807-815
-        const double nrm = std::sqrt(nrm2[e]);
-        factors[e] = (nrm > 0.0 ? 1.0 / nrm : 1.0) * (1.0 / phase);  // :816
-      }
-      for (auto& s : b->sh) {
-        HIPCHK(hipMemcpyAsync(s.hbuf, factors, sizeof(double) * ne, hipMemcpyHostToDevice, c->stream));
-        launch_scale_columns(c->stream, s.X, s.ldv, ne, s.nloc, s.hbuf);
-        for (int e = 0; e < ne; ++e)
-          HIPCHK(hipMemcpyAsync(X + (size_t)(e0 + e) * ldx + (s.rb - b->sh[0].rb), s.X + (size_t)e * s.ldv, sizeof(double) * s.nloc, hipMemcpyDeviceToHost, c->stream));
-      }
+      CHK(ritz_raw(b, nvec, ne, cols, d_S));
+      double nrm2[E];
+      HIPCHK(hipMemcpyAsync(nrm2, b->sh[0].hbuf, sizeof(double) * ne, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));
+      CHK(ritz_finish(b, bufs, lds_, b->es, ne, nrm2, X, ldx, e0));
     }
     return 0;
   }();
@@ -1436,7 +1508,8 @@ int eigenex_ritz_vectors(eigenex_basis_t b, int nvec, int nev, const double* S, 
   return rc;
 }
 
-// complex coefficients (arnoldi.hpp:841-865): 4 complex columns per pass over the basis
+// complex coefficients (arnoldi.hpp:841-865): 4 complex columns per pass over the basis; the basis may be
+// real (real operator, complex Ritz pairs) or complex.  X: interleaved (re, im), column stride ldx entries.
 int eigenex_ritz_vectors_complex(eigenex_basis_t b, int nvec, int nev, const double* S_re, const double* S_im, int lds,
                                  double* X, int64_t ldx) {
   if (!b || nvec < 0 || nvec > b->cap || nev < 0 || (nev && (!S_re || !S_im || !X)) || lds < nvec) return fail(EIGENEX_ERR_ARG, "eigenex_ritz_vectors_complex: bad argument");
@@ -1450,10 +1523,12 @@ int eigenex_ritz_vectors_complex(eigenex_basis_t b, int nvec, int nev, const dou
   HIPCHK(hipMalloc(&d_S, sizeof(double) * (size_t)std::max(nvec, 1) * E));
   std::vector<double*> outbuf(b->sh.size(), nullptr);
   int rc = [&]() -> int {
+    std::vector<int64_t> ldo;
     for (size_t i = 0; i < b->sh.size(); ++i) {
       BasisShard& s = b->sh[i];
-      if (!s.X) HIPCHK(hipMalloc(&s.X, sizeof(double) * (size_t)s.ldv * E));
-      HIPCHK(hipMalloc(&outbuf[i], sizeof(double) * (size_t)s.ldv * E));
+      if (!s.X) HIPCHK(hipMalloc(&s.X, sizeof(double) * (size_t)s.ldd * E));
+      HIPCHK(hipMalloc(&outbuf[i], sizeof(double) * (size_t)s.ldv * 2 * EC));
+      ldo.push_back(s.ldv * 2);
     }
     for (int e0 = 0; e0 < nev; e0 += EC) {
       const int nc = std::min(EC, nev - e0);
@@ -1462,34 +1537,18 @@ int eigenex_ritz_vectors_complex(eigenex_basis_t b, int nvec, int nev, const dou
         cols[2 * e] = S_re + (size_t)(e0 + e) * lds;
         cols[2 * e + 1] = S_im + (size_t)(e0 + e) * lds;
       }
-      double nrm2[E], frow[E], fval[E], factors[E];
-      CHK(ritz_chunk(b, nvec, 2 * nc, cols, d_S, nrm2, frow, fval));
-      for (int e = 0; e < nc; ++e) {
-        // first entry with |z| > 0: the earlier of the first non-zero real / imaginary parts
-        const double r0 = std::min(frow[2 * e], frow[2 * e + 1]);
-        double pr = 1.0, pi = 0.0;
-        if (r0 < (double)b->n_global) {
-          const double zr = frow[2 * e] == r0 ? fval[2 * e] : 0.0;
-          const double zi = frow[2 * e + 1] == r0 ? fval[2 * e + 1] : 0.0;
-          const double az = std::hypot(zr, zi);
-          pr = zr / az;  // phase_factor = value / abs  (arnoldi.hpp:855-862)
-          pi = zi / az;
-        }
-        const double nrm = std::sqrt(nrm2[2 * e] + nrm2[2 * e + 1]);
-        const double inv = nrm > 0.0 ? 1.0 / nrm : 1.0;
-        // (1/phase) * normalized = conj(phase) * x / nrm   (|phase| = 1)
-        factors[2 * e] = pr * inv;
-        factors[2 * e + 1] = -pi * inv;
-      }
+      CHK(ritz_raw(b, nvec, 2 * nc, cols, d_S));
+      // x_e = (V s_re) + i (V s_im), squared norms of the combined columns
       for (size_t i = 0; i < b->sh.size(); ++i) {
         BasisShard& s = b->sh[i];
-        HIPCHK(hipMemcpyAsync(s.hbuf, factors, sizeof(double) * 2 * nc, hipMemcpyHostToDevice, c->stream));
-        launch_complex_finish(c->stream, s.X, s.ldv, nc, s.nloc, s.hbuf, outbuf[i], s.ldv);
-        for (int e = 0; e < nc; ++e)
-          HIPCHK(hipMemcpyAsync(X + 2 * ((size_t)(e0 + e) * ldx + (s.rb - b->sh[0].rb)), outbuf[i] + 2 * (size_t)e * s.ldv,
-                                sizeof(double) * 2 * s.nloc, hipMemcpyDeviceToHost, c->stream));
+        launch_ritz_combine(c->stream, s.X, s.ldd, nc, s.nloc, s.es, outbuf[i], s.ldv, s.partials, s.pstride, s.g_vec);
+        launch_reduce(c->stream, s.partials, s.pstride, s.g_vec, nc, s.hbuf, s.ctrl_zero);
       }
+      CHK(allreduce(b, 0, nc));
+      double nrm2[E];
+      HIPCHK(hipMemcpyAsync(nrm2, b->sh[0].hbuf, sizeof(double) * nc, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));
+      CHK(ritz_finish(b, outbuf, ldo, 2, nc, nrm2, X, ldx, e0));
     }
     return 0;
   }();

@@ -12,7 +12,10 @@
  * Conventions
  *   - plain C, opaque handles, no C++/torch types; every function returns an
  *     int status: 0 = ok, negative = error (eigenex_last_error() has the text).
- *   - all data are real fp64; indices int32 (per-shard nnz < 2^31); sizes int64.
+ *   - scalars are fp64, real or complex: complex data (the *_z entry points, or any basis created
+ *     complex) are interleaved (re, im) pairs, i.e. the memory layout of std::complex<double>,
+ *     passed as double*; alpha, beta, norms, thresholds and the Lanczos shift are always real.
+ *     Indices int32 (per-shard nnz < 2^31); sizes int64.
  *   - a context owns ONE HIP stream; every call on its handles is ordered on
  *     that stream.  Calls that return scalars/vectors to the host synchronise;
  *     the *_enqueue calls do not.
@@ -121,6 +124,11 @@ int eigenex_profile_get(eigenex_context_t ctx, int kind, int64_t* launches, doub
  * Replaces the user lambda behind setMatrixMultiplication (lanczos.hpp:179-188). */
 int eigenex_csr_upload(eigenex_context_t ctx, int64_t n_global, int64_t row_begin, int64_t n_rows,
                        const int32_t* rowptr, const int32_t* col_global, const double* val, eigenex_csr_t* out);
+/* the same with complex values: val_interleaved[2*nnz] = (re, im) pairs (Scalar = std::complex<double>,
+ * the instantiation of the reference's own samples: src/samples/sample_lanczos2.cpp:14, sample_arnoldi.cpp:14) */
+int eigenex_csr_upload_z(eigenex_context_t ctx, int64_t n_global, int64_t row_begin, int64_t n_rows,
+                         const int32_t* rowptr, const int32_t* col_global, const double* val_interleaved,
+                         eigenex_csr_t* out);
 /* synthetic 7-point Laplacian on an n^3 grid generated on the device (BASELINE configs 2 and 4) */
 int eigenex_csr_laplacian3d(eigenex_context_t ctx, int64_t n, eigenex_csr_t* out);
 int eigenex_csr_destroy(eigenex_csr_t csr);
@@ -132,11 +140,19 @@ int eigenex_csr_info(eigenex_csr_t csr, int64_t* n_global, int64_t* n_local, int
  * csr may be NULL: the operator is then a host callback (single shard only). */
 int eigenex_basis_create(eigenex_context_t ctx, eigenex_csr_t csr, int64_t n_global, int capacity, int n_ortho,
                          eigenex_basis_t* out);
+/* explicit scalar type (needed when csr == NULL: host-callback operator); with a csr it must match it.
+ * eigenex_basis_create == eigenex_basis_create_ex with is_complex taken from the csr (real if csr == NULL). */
+int eigenex_basis_create_ex(eigenex_context_t ctx, eigenex_csr_t csr, int64_t n_global, int capacity, int n_ortho,
+                            int is_complex, eigenex_basis_t* out);
+int eigenex_basis_is_complex(eigenex_basis_t b, int* is_complex);
 int eigenex_basis_destroy(eigenex_basis_t b);
 int eigenex_basis_set_host_operator(eigenex_basis_t b, eigenex_matvec_fn fn, void* user);
 /* settings of LanczosBase/ArnoldiBase that the kernels need (lanczos.hpp:155-159) */
 int eigenex_basis_configure(eigenex_basis_t b, double eigenvalue_shift, double threshold,
                             int64_t reorthogonalize_interval, int ortho_mode);
+/* complex eigenvalueShift_ (ArnoldiBase, arnoldi.hpp:108: the shift is a Scalar there) */
+int eigenex_basis_configure_z(eigenex_basis_t b, double shift_re, double shift_im, double threshold,
+                              int64_t reorthogonalize_interval, int ortho_mode);
 /* grow the basis slab to hold at least `capacity` vectors, keeping the state (the reference's
  * std::vector<VectorType>::push_back never runs out: lanczos.hpp:402, arnoldi.hpp:364) */
 int eigenex_basis_reserve(eigenex_basis_t b, int capacity);
@@ -151,7 +167,9 @@ int eigenex_vec_download(eigenex_basis_t b, int vec_ref, double* host);
 int eigenex_vec_copy(eigenex_basis_t b, int dst_ref, int src_ref);
 
 /* ---- step primitives (each one parity-tested on its own; all synchronise) -- */
-/* y = A*x + shift*x ; if dot != NULL also *dot = x . y      (a1, a2, a3 of SURVEY 8a) */
+/* Complex bases: h / dot arguments hold (re, im) pairs (dots are conjugate-linear in the basis vector,
+ * Eigen's a.dot(b) = sum conj(a_i) b_i); host vectors are interleaved.
+ * y = A*x + shift*x ; if dot != NULL also *dot = x . y      (a1, a2, a3 of SURVEY 8a) */
 int eigenex_apply(eigenex_basis_t b, int x_ref, int y_ref, double shift, double* dot);
 /* h[i] = col(first + i*stride) . w, i < count, then h[count + q] = ortho(q) . w, q < n_ortho_used   (a5 dot half) */
 int eigenex_dots(eigenex_basis_t b, int w_ref, int first, int stride, int count, int n_ortho_used, double* h);
@@ -182,16 +200,17 @@ typedef struct {
   double residue;      /* Arnoldi residue_ */
 } eigenex_state_t;
 
-/* synchronises and returns the coefficients: Lanczos alpha[nalpha], beta[nbeta];
- * Arnoldi: hess column-major with leading dimension ldh (>= nalpha+1): hess[r + c*ldh] = h_[c][r].
+/* synchronises and returns the coefficients: Lanczos alpha[nalpha], beta[nbeta] (real);
+ * Arnoldi: hess column-major with leading dimension ldh (>= nalpha+1): hess[r + c*ldh] = h_[c][r]
+ * (complex basis: (re, im) pairs, i.e. 2*ldh doubles per column).
  * Any output pointer may be NULL. */
 int eigenex_lanczos_state(eigenex_basis_t b, eigenex_state_t* st, double* alpha, double* beta);
 int eigenex_arnoldi_state(eigenex_basis_t b, eigenex_state_t* st, double* hess, int ldh);
 
-/* X[:, e] = sum_m S[m + e*lds] * col(m), m < nvec, e < nev; then each column is
- * normalised and divided by the sign of its first non-zero entry
- * (lanczos.hpp:798-816).  X is returned to the host (rows owned by this context),
- * leading dimension ldx. */
+/* X[:, e] = sum_m S[m + e*lds] * col(m), m < nvec, e < nev (S real: eigenvectors of the tridiagonal
+ * matrix); then each column is normalised and divided by the phase z/|z| of its first non-zero entry
+ * (lanczos.hpp:798-816).  X is returned to the host (rows owned by this context), leading dimension
+ * ldx entries; it has the basis' scalar type (interleaved complex for a complex basis). */
 int eigenex_ritz_vectors(eigenex_basis_t b, int nvec, int nev, const double* S, int lds, double* X, int64_t ldx);
 /* complex coefficients (Arnoldi, arnoldi.hpp:841-865): S_re/S_im column-major nvec x nev (leading dimension lds);
  * X receives interleaved (re,im) pairs, i.e. std::complex<double>[ldx * nev]; each column is normalised and divided by

@@ -359,3 +359,156 @@ def test_rccl_calls_on_single_rank_communicator(capi):
     np.testing.assert_allclose(beta, ref.beta, atol=1e-12)
     assert ctx.profile_get(capi.K_COMM)[0] >= 3 * m  # the collectives really ran
     ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# complex fp64 (the scalar type of the reference's own samples)
+# ---------------------------------------------------------------------------------------------
+def _hermitian_csr(rng, n, per):
+    """random sparse Hermitian matrix in CSR (complex128), sorted columns"""
+    import scipy.sparse as sp
+
+    A = sp.random(n, n, density=per / n, random_state=np.random.RandomState(int(rng.integers(1 << 30))), format="coo")
+    A = sp.coo_matrix((A.data + 1j * rng.standard_normal(A.data.size), (A.row, A.col)), shape=(n, n))
+    H = (A + A.conj().T).tocsr()
+    H.sort_indices()
+    return H.indptr.astype(np.int32), H.indices.astype(np.int32), H.data.astype(np.complex128), H
+
+
+@pytest.mark.parametrize("shards", [1, 3])
+def test_complex_primitives(capi, shards):
+    rng = np.random.default_rng(77)
+    n = 4099
+    rowptr, col, val, H = _hermitian_csr(rng, n, 9)
+    ctx = capi.Context(loopback_shards=shards) if shards > 1 else capi.Context()
+    A = capi.Csr.upload(ctx, n, rowptr, col, val)
+    cap, nq = 7, 2
+    b = capi.Basis(ctx, A, n, cap, nq)
+    assert b.is_complex
+    V = rng.standard_normal((cap, n)) + 1j * rng.standard_normal((cap, n))
+    Q = rng.standard_normal((nq, n)) + 1j * rng.standard_normal((nq, n))
+    w = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    for c in range(cap):
+        b.upload(capi.VEC_COL(c), V[c])
+    for q in range(nq):
+        b.upload(capi.VEC_ORTHO(q), Q[q])
+    b.upload(capi.VEC_W, w)
+    # operator: y = H w (+ shift w), dot = conj(w).y
+    dot = b.apply(capi.VEC_W, capi.VEC_V, 0.5, want_dot=True)
+    y_ref = H @ w + 0.5 * w
+    y = b.download(capi.VEC_V)
+    np.testing.assert_allclose(y, y_ref, rtol=0, atol=1e-13 * np.abs(y_ref).max())
+    assert abs(dot - np.vdot(w, y_ref)) < 1e-12 * abs(np.vdot(w, y_ref))
+    # dots are conjugate-linear in the basis vector; update subtracts h_c * col_c
+    h = b.dots(capi.VEC_W, 1, 2, 3, 2)
+    M = np.concatenate([V[[1, 3, 5]], Q])
+    h_ref = M.conj() @ w
+    assert np.abs(h - h_ref).max() < 1e-12 * np.linalg.norm(w) * np.linalg.norm(M, axis=1).max()
+    b.upload(capi.VEC_V, w)
+    nrm2 = b.update(capi.VEC_V, 1, 2, 3, h_ref, 2)
+    w_new = w - h_ref @ M
+    got = b.download(capi.VEC_V)
+    np.testing.assert_allclose(got, w_new, rtol=0, atol=1e-11)
+    assert abs(nrm2 - np.vdot(got, got).real) < 1e-12 * nrm2
+    ctx.close()
+
+
+@pytest.mark.parametrize("shards", [1, 2])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_complex_lanczos_and_arnoldi_steps_match_oracle(capi, shards, mode):
+    rng = np.random.default_rng(5)
+    n, m = 3000, 30
+    rowptr, col, val, H = _hermitian_csr(rng, n, 7)
+    init = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    q0 = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    q0 /= np.linalg.norm(q0)
+    # Lanczos (Hermitian operator): numpy oracle, complex128
+    bo = ko.LanczosBaseOracle(np.complex128)
+    bo.matmul = lambda x: H @ x
+    bo.matrix_height = n
+    bo.initial_vector = init
+    bo.orthogonalizing_vectors = [q0]
+    bo.eigenvalue_shift = -0.3
+    for _ in range(m + 1):
+        assert bo.update_lanczos_steps()
+    ctx = capi.Context(loopback_shards=shards) if shards > 1 else capi.Context()
+    A = capi.Csr.upload(ctx, n, rowptr, col, val)
+    b = capi.Basis(ctx, A, n, m + 1, 1)
+    b.configure(-0.3, 1e-12, 1, mode)
+    b.upload(capi.VEC_ORTHO(0), q0)
+    b.upload(capi.VEC_W, init)
+    b.lanczos_enqueue(m + 1)
+    st, alpha, beta = b.lanczos_state()
+    assert st.nvec == m + 1 and st.stopped == 0
+    np.testing.assert_allclose(alpha, bo.alpha, rtol=0, atol=1e-11)
+    np.testing.assert_allclose(beta, bo.beta, rtol=0, atol=1e-11)
+    V = np.stack([b.download(capi.VEC_COL(c)) for c in range(m + 1)])
+    assert np.abs(V.conj() @ V.T - np.eye(m + 1)).max() < 1e-12
+    assert np.abs(V.conj() @ q0).max() < 1e-12
+    # Ritz vectors with real S on a complex basis: first entry real positive, unit norm
+    th, S = ko.tridiagonal_eigh(alpha, beta)
+    X = b.ritz_vectors(m + 1, S[:, :3])
+    for e in range(3):
+        x_ref = ko.fix_phase_and_normalize(V.T @ S[:, e])
+        np.testing.assert_allclose(X[:, e], x_ref, rtol=0, atol=1e-12)
+    b.close()
+    # Arnoldi on a non-Hermitian complex operator with a complex shift (Scalar shift, arnoldi.hpp:108)
+    val2 = val * (1.0 + 0.3j * rng.standard_normal(val.size))
+    import scipy.sparse as sp
+
+    G = sp.csr_matrix((val2, col, rowptr), shape=(n, n))
+    ao = ko.ArnoldiBaseOracle(np.complex128)
+    ao.matmul = lambda x: G @ x
+    ao.matrix_height = n
+    ao.initial_vector = init
+    ao.orthogonalizing_vectors = [q0]
+    ao.eigenvalue_shift = 0.2 - 0.1j
+    for _ in range(m):
+        assert ao.update_arnoldi_steps()
+    A2 = capi.Csr.upload(ctx, n, rowptr, col, val2)
+    b = capi.Basis(ctx, A2, n, m, 1)
+    b.configure(0.2 - 0.1j, 1e-12, 1, mode)
+    b.upload(capi.VEC_ORTHO(0), q0)
+    b.upload(capi.VEC_W, init)
+    b.arnoldi_enqueue(m)
+    st, Hh = b.arnoldi_state()
+    assert st.nvec == m and st.iterations == m
+    np.testing.assert_allclose(Hh, ao.make_hessenberg_matrix(), rtol=0, atol=1e-10)
+    assert abs(st.residue - ao.residue) < 1e-10
+    # complex coefficients on a complex basis
+    vals, Sc = np.linalg.eig(Hh)
+    X = b.ritz_vectors(m, Sc[:, :5])
+    Vq = np.stack([b.download(capi.VEC_COL(c)) for c in range(m)])
+    for e in range(5):
+        np.testing.assert_allclose(X[:, e], ko.fix_phase_and_normalize(Vq.T @ Sc[:, e]), rtol=0, atol=1e-12)
+    ctx.close()
+
+
+def test_complex_host_operator(capi):
+    """reference sample_lanczos2.cpp: n = 200 Hermitian +-i tridiagonal as a host callback, complex128"""
+    n = 200
+    Hd = np.zeros((n, n), np.complex128)
+    i = np.arange(n - 1)
+    Hd[i, i + 1] = -1j
+    Hd[i + 1, i] = 1j
+    rng = np.random.default_rng(1)
+    init = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    bo = ko.LanczosBaseOracle(np.complex128)
+    bo.matmul = lambda x: Hd @ x
+    bo.matrix_height = n
+    bo.initial_vector = init
+    bo.threshold = 1e-14
+    m = 60
+    for _ in range(m + 1):
+        assert bo.update_lanczos_steps()
+    ctx = capi.Context()
+    b = capi.Basis(ctx, None, n, m + 1, 0, dtype=np.complex128)
+    b.configure(0.0, 1e-14, 1, 0)
+    b.set_host_operator(lambda x: Hd @ x)
+    b.upload(capi.VEC_W, init)
+    b.lanczos_enqueue(m + 1)
+    st, alpha, beta = b.lanczos_state()
+    assert st.nvec == m + 1
+    np.testing.assert_allclose(alpha, bo.alpha, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(beta, bo.beta, rtol=0, atol=1e-12)
+    ctx.close()
