@@ -3,6 +3,14 @@
 // without a C++ front-end (ctypes in tests/ and bench.py, cgo, JNI ...) can drive
 // the same code a C++ user of the reference API would compile.  Host-only code:
 // all device work goes through libeigenex_hip.so.
+//
+// Four families of entry points, one per instantiation:
+//   eigenex_lanczos_solver_*   LanczosEigenSolver<double>
+//   eigenex_zlanczos_solver_*  LanczosEigenSolver<std::complex<double>>
+//   eigenex_arnoldi_solver_*   ArnoldiEigenSolver<double>
+//   eigenex_zarnoldi_solver_*  ArnoldiEigenSolver<std::complex<double>>
+// Complex data cross this boundary as interleaved (re, im) doubles.
+#include <complex>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -16,19 +24,11 @@ using namespace cmpt::EigenEx;
 namespace {
 thread_local std::string g_serr;
 
-struct LanczosBox {
+template <class Solver>
+struct Box {
   std::shared_ptr<device::Context> ctx;
   std::shared_ptr<device::CsrOperator> op;
-  LanczosEigenSolver<double> es;
-  eigenex_matvec_fn fn = nullptr;
-  void* user = nullptr;
-};
-struct ArnoldiBox {
-  std::shared_ptr<device::Context> ctx;
-  std::shared_ptr<device::CsrOperator> op;
-  ArnoldiEigenSolver<double> es;
-  eigenex_matvec_fn fn = nullptr;
-  void* user = nullptr;
+  Solver es;
 };
 
 template <class F>
@@ -42,21 +42,185 @@ int guard(F&& f) {
   }
 }
 
-template <class Box>
-void set_common(Box* b, const char* key, double v) {
-  const std::string k(key);
-  auto& es = b->es;
+template <class S>
+constexpr int es_of() {
+  return detail::IsComplex<S>::value ? 2 : 1;
+}
+
+template <class S>
+DenseVector<S> make_vector(const double* p, int64_t n) {
+  return DenseVector<S>(reinterpret_cast<const S*>(p), (Index)n);
+}
+
+template <class Solver>
+void set_common(Solver& es, const std::string& k, double v) {
   if (k == "minIterations") es.setMinIterations((Index)v);
   else if (k == "maxIterations") es.setMaxIterations((Index)v);
   else if (k == "tolerance") es.setTolerance(v);
   else if (k == "maxEigenvalues") es.setMaxEigenvalues((Index)v);
   else if (k == "computeEigenvectorsOn") es.setComputeEigenvectorsOn(v != 0.0);
   else if (k == "reserveSize") es.setReserveSize((Index)v);
-  else if (k == "eigenvalueShift") es.setEigenvalueShift(v);
   else if (k == "threshold") es.setThreshold(v);
   else if (k == "orthogonalization") es.setOrthogonalization(v != 0.0 ? Orthogonalization::Sequential : Orthogonalization::Batched);
   else throw LanczosException("unknown setting: " + k);
 }
+
+inline void assign_shift(double& dst, double re, double) { dst = re; }
+inline void assign_shift(std::complex<double>& dst, double re, double im) { dst = std::complex<double>(re, im); }
+
+template <class Solver>
+int sv_set_device_operator(void* p, eigenex_context_t ctx, eigenex_csr_t csr) {
+  return guard([&] {
+    auto* b = static_cast<Box<Solver>*>(p);
+    b->ctx = device::Context::borrow(ctx);
+    b->op = device::CsrOperator::borrow(b->ctx, csr);
+    b->es.setDeviceOperator(b->op);
+  });
+}
+
+template <class Solver>
+int sv_set_host_operator(void* p, eigenex_context_t ctx, eigenex_matvec_fn fn, void* user, int64_t height) {
+  using S = typename Solver::Scalar;
+  return guard([&] {
+    auto* b = static_cast<Box<Solver>*>(p);
+    if (ctx) {
+      b->ctx = device::Context::borrow(ctx);
+      b->es.setDeviceContext(b->ctx);
+    }
+    b->es.setMatrixMultiplication(
+        [fn, user](const S* in, S* out) { fn(reinterpret_cast<const double*>(in), reinterpret_cast<double*>(out), user); }, (Index)height);
+  });
+}
+
+template <class Solver>
+int sv_set_vectors(void* p, const double* vecs, int64_t n, int count) {
+  using S = typename Solver::Scalar;
+  return guard([&] {
+    std::vector<DenseVector<S>> q;
+    for (int i = 0; i < count; ++i) q.push_back(make_vector<S>(vecs + (size_t)i * n * es_of<S>(), n));
+    static_cast<Box<Solver>*>(p)->es.setOrthogonalizingVectors(std::move(q));
+  });
+}
+
+template <class Solver>
+const char* sv_log_line(void* p, int64_t i) {
+  auto& lg = static_cast<Box<Solver>*>(p)->es.log();
+  return (i >= 0 && i < (int64_t)lg.size()) ? lg[(size_t)i].c_str() : "";
+}
+
+// ---- Lanczos ---------------------------------------------------------------------------
+template <class S>
+int lz_set(void* p, const char* key, double v, double v_im) {
+  using Solver = LanczosEigenSolver<S>;
+  (void)v_im;
+  return guard([&] {
+    auto& es = static_cast<Box<Solver>*>(p)->es;
+    const std::string k(key);
+    if (k == "reorthogonalizeInterval") es.setReorthogonalizeInterval((Index)v);
+    else if (k == "eigenvalueShift") es.setEigenvalueShift(v);
+    else set_common(es, k, v);
+  });
+}
+
+// sizes: [iterations, nvec, nalpha, nbeta, neigenvalues, eigvec_rows, eigvec_cols, nlog, info, hasWARN, hasERROR]
+template <class S>
+int lz_sizes(void* p, int64_t* out) {
+  return guard([&] {
+    auto& es = static_cast<Box<LanczosEigenSolver<S>>*>(p)->es;
+    out[0] = es.iterations();
+    out[1] = es.lanczosBase().lanczosvectorsSize();
+    out[2] = (int64_t)es.alpha().size();
+    out[3] = (int64_t)es.beta().size();
+    out[4] = es.eigenvalues().size();
+    out[5] = es.eigenvectors().rows();
+    out[6] = es.eigenvectors().cols();
+    out[7] = (int64_t)es.log().size();
+    out[8] = (int64_t)es.info();
+    out[9] = es.hasWARN();
+    out[10] = es.hasERROR();
+  });
+}
+
+template <class S>
+int lz_get(void* p, double* alpha, double* beta, double* eigenvalues, double* eigenvectors) {
+  return guard([&] {
+    auto& es = static_cast<Box<LanczosEigenSolver<S>>*>(p)->es;
+    if (alpha) std::copy(es.alpha().begin(), es.alpha().end(), alpha);
+    if (beta) std::copy(es.beta().begin(), es.beta().end(), beta);
+    if (eigenvalues) std::copy(es.eigenvalues().begin(), es.eigenvalues().end(), eigenvalues);
+    if (eigenvectors && es.eigenvectors().size())
+      std::memcpy(eigenvectors, es.eigenvectors().data(), sizeof(S) * (size_t)es.eigenvectors().size());
+  });
+}
+
+template <class S>
+int lz_vector(void* p, int64_t k, double* out) {
+  return guard([&] {
+    const auto& v = static_cast<Box<LanczosEigenSolver<S>>*>(p)->es.lanczosvectors();
+    if (k < 0 || k >= (int64_t)v.size()) throw LanczosException("vector index out of range");
+    std::memcpy(out, v[(size_t)k].data(), sizeof(S) * (size_t)v[(size_t)k].size());
+  });
+}
+
+template <class S>
+int64_t lz_convergence_log(void* p, int64_t index, double* out, int64_t cap) {
+  auto& cl = static_cast<Box<LanczosEigenSolver<S>>*>(p)->es.convergenceLog();
+  auto it = cl.find((Index)index);
+  if (it == cl.end()) return 0;
+  for (int64_t i = 0; i < (int64_t)it->second.size() && i < cap; ++i) out[i] = it->second[(size_t)i];
+  return (int64_t)it->second.size();
+}
+
+// ---- Arnoldi ------------------------------------------------------------------------------
+template <class S>
+int ar_set(void* p, const char* key, double v, double v_im) {
+  using Solver = ArnoldiEigenSolver<S>;
+  return guard([&] {
+    auto& es = static_cast<Box<Solver>*>(p)->es;
+    const std::string k(key);
+    if (k == "eigenvalueShift") {
+      S sh;
+      assign_shift(sh, v, v_im);
+      es.setEigenvalueShift(sh);
+    } else {
+      set_common(es, k, v);
+    }
+  });
+}
+
+// sizes: [iterations, nvec, hess_rows, neigenvalues, eigvec_rows, eigvec_cols, nlog, info, hasWARN, hasERROR]
+template <class S>
+int ar_sizes(void* p, int64_t* out) {
+  return guard([&] {
+    auto& es = static_cast<Box<ArnoldiEigenSolver<S>>*>(p)->es;
+    out[0] = es.iterations();
+    out[1] = es.arnoldiBase().arnoldivectorsSize();
+    out[2] = es.hessenbergMatrix().rows();
+    out[3] = es.eigenvalues().size();
+    out[4] = es.eigenvectors().rows();
+    out[5] = es.eigenvectors().cols();
+    out[6] = (int64_t)es.log().size();
+    out[7] = (int64_t)es.info();
+    out[8] = es.hasWARN();
+    out[9] = es.hasERROR();
+  });
+}
+
+// hess: column-major Scalar; eigenvalues / eigenvectors complex (interleaved)
+template <class S>
+int ar_get(void* p, double* hess, double* eigenvalues, double* eigenvectors, double* residue) {
+  return guard([&] {
+    auto& es = static_cast<Box<ArnoldiEigenSolver<S>>*>(p)->es;
+    if (hess && es.hessenbergMatrix().size())
+      std::memcpy(hess, es.hessenbergMatrix().data(), sizeof(S) * (size_t)es.hessenbergMatrix().size());
+    if (eigenvalues && es.eigenvalues().size())
+      std::memcpy(eigenvalues, es.eigenvalues().data(), sizeof(double) * 2 * (size_t)es.eigenvalues().size());
+    if (eigenvectors && es.eigenvectors().size())
+      std::memcpy(eigenvectors, es.eigenvectors().data(), sizeof(double) * 2 * (size_t)es.eigenvectors().size());
+    if (residue) *residue = es.arnoldiBase().residue();
+  });
+}
+
 }  // namespace
 
 extern "C" {
@@ -79,6 +243,14 @@ int eigenex_solver_random_vector(uint32_t seed, int64_t n, double* out) {
     std::copy(v.begin(), v.end(), out);
   });
 }
+// complex: real part then imaginary part per entry (util.hpp:76-97); out interleaved
+int eigenex_solver_random_vector_z(uint32_t seed, int64_t n, double* out) {
+  return guard([&] {
+    std::mt19937 g(seed);
+    auto v = LanczosBase<std::complex<double>>::makeRandomVector(g, (Index)n);
+    std::memcpy(out, v.data(), sizeof(double) * 2 * (size_t)n);
+  });
+}
 // small dense solvers (small_eigen.hpp); vectors may be NULL
 int eigenex_solver_tridiagonal_eigen(int n, const double* diag, const double* sub, double* values, double* vectors) {
   return guard([&] {
@@ -99,181 +271,52 @@ int eigenex_solver_hessenberg_eigen(int n, const double* H_interleaved, double* 
   });
 }
 
-// ---- Lanczos -----------------------------------------------------------------------------
-void* eigenex_lanczos_solver_create(void) {
-  try {
-    return new LanczosBox();
-  } catch (const std::exception& e) {
-    g_serr = e.what();
-    return nullptr;
-  }
-}
-void eigenex_lanczos_solver_destroy(void* p) { delete static_cast<LanczosBox*>(p); }
+#define EIGENEX_SOLVER_COMMON(PFX, SOLVER)                                                                              \
+  void* PFX##create(void) {                                                                                             \
+    try {                                                                                                               \
+      return new Box<SOLVER>();                                                                                         \
+    } catch (const std::exception& e) {                                                                                 \
+      g_serr = e.what();                                                                                                \
+      return nullptr;                                                                                                   \
+    }                                                                                                                   \
+  }                                                                                                                     \
+  void PFX##destroy(void* p) { delete static_cast<Box<SOLVER>*>(p); }                                                   \
+  int PFX##set_device_operator(void* p, eigenex_context_t ctx, eigenex_csr_t csr) {                                     \
+    return sv_set_device_operator<SOLVER>(p, ctx, csr);                                                                 \
+  }                                                                                                                     \
+  int PFX##set_host_operator(void* p, eigenex_context_t ctx, eigenex_matvec_fn fn, void* user, int64_t height) {        \
+    return sv_set_host_operator<SOLVER>(p, ctx, fn, user, height);                                                      \
+  }                                                                                                                     \
+  int PFX##set_indices_for_convergence(void* p, const int64_t* idx, int n) {                                            \
+    return guard([&] { static_cast<Box<SOLVER>*>(p)->es.setIndicesForConvergence(std::vector<Index>(idx, idx + n)); }); \
+  }                                                                                                                     \
+  int PFX##set_initial_vector(void* p, const double* v, int64_t n) {                                                    \
+    return guard([&] { static_cast<Box<SOLVER>*>(p)->es.setInitialVector(make_vector<SOLVER::Scalar>(v, n)); });        \
+  }                                                                                                                     \
+  int PFX##set_orthogonalizing_vectors(void* p, const double* vecs, int64_t n, int count) {                             \
+    return sv_set_vectors<SOLVER>(p, vecs, n, count);                                                                   \
+  }                                                                                                                     \
+  int PFX##compute(void* p) { return guard([&] { static_cast<Box<SOLVER>*>(p)->es.compute(); }); }                      \
+  int PFX##continue(void* p) { return guard([&] { static_cast<Box<SOLVER>*>(p)->es.continueToCompute(); }); }           \
+  const char* PFX##log_line(void* p, int64_t i) { return sv_log_line<SOLVER>(p, i); }
 
-int eigenex_lanczos_solver_set_device_operator(void* p, eigenex_context_t ctx, eigenex_csr_t csr) {
-  return guard([&] {
-    auto* b = static_cast<LanczosBox*>(p);
-    b->ctx = device::Context::borrow(ctx);
-    b->op = device::CsrOperator::borrow(b->ctx, csr);
-    b->es.setDeviceOperator(b->op);
-  });
-}
-int eigenex_lanczos_solver_set_host_operator(void* p, eigenex_context_t ctx, eigenex_matvec_fn fn, void* user, int64_t height) {
-  return guard([&] {
-    auto* b = static_cast<LanczosBox*>(p);
-    if (ctx) {
-      b->ctx = device::Context::borrow(ctx);
-      b->es.setDeviceContext(b->ctx);
-    }
-    b->fn = fn;
-    b->user = user;
-    b->es.setMatrixMultiplication([fn, user](const double* in, double* out) { fn(in, out, user); }, (Index)height);
-  });
-}
-int eigenex_lanczos_solver_set(void* p, const char* key, double v) {
-  return guard([&] {
-    auto* b = static_cast<LanczosBox*>(p);
-    if (std::string(key) == "reorthogonalizeInterval") b->es.setReorthogonalizeInterval((Index)v);
-    else set_common(b, key, v);
-  });
-}
-int eigenex_lanczos_solver_set_indices_for_convergence(void* p, const int64_t* idx, int n) {
-  return guard([&] { static_cast<LanczosBox*>(p)->es.setIndicesForConvergence(std::vector<Index>(idx, idx + n)); });
-}
-int eigenex_lanczos_solver_set_initial_vector(void* p, const double* v, int64_t n) {
-  return guard([&] { static_cast<LanczosBox*>(p)->es.setInitialVector(DenseVector<double>(v, (Index)n)); });
-}
-int eigenex_lanczos_solver_set_orthogonalizing_vectors(void* p, const double* vecs, int64_t n, int count) {
-  return guard([&] {
-    std::vector<DenseVector<double>> q;
-    for (int i = 0; i < count; ++i) q.emplace_back(vecs + (size_t)i * n, (Index)n);
-    static_cast<LanczosBox*>(p)->es.setOrthogonalizingVectors(std::move(q));
-  });
-}
-int eigenex_lanczos_solver_compute(void* p) { return guard([&] { static_cast<LanczosBox*>(p)->es.compute(); }); }
-int eigenex_lanczos_solver_continue(void* p) { return guard([&] { static_cast<LanczosBox*>(p)->es.continueToCompute(); }); }
+#define EIGENEX_LANCZOS_FAMILY(PFX, S)                                                                                  \
+  EIGENEX_SOLVER_COMMON(PFX, LanczosEigenSolver<S>)                                                                     \
+  int PFX##set(void* p, const char* key, double v, double v_im) { return lz_set<S>(p, key, v, v_im); }                  \
+  int PFX##sizes(void* p, int64_t* out) { return lz_sizes<S>(p, out); }                                                 \
+  int PFX##get(void* p, double* a, double* b, double* ev, double* X) { return lz_get<S>(p, a, b, ev, X); }              \
+  int PFX##lanczosvector(void* p, int64_t k, double* out) { return lz_vector<S>(p, k, out); }                           \
+  int64_t PFX##convergence_log(void* p, int64_t i, double* out, int64_t cap) { return lz_convergence_log<S>(p, i, out, cap); }
 
-// sizes: [iterations, nvec, nalpha, nbeta, neigenvalues, eigvec_rows, eigvec_cols, nlog, info, hasWARN, hasERROR]
-int eigenex_lanczos_solver_sizes(void* p, int64_t* out) {
-  return guard([&] {
-    auto& es = static_cast<LanczosBox*>(p)->es;
-    out[0] = es.iterations();
-    out[1] = es.lanczosBase().lanczosvectorsSize();
-    out[2] = (int64_t)es.alpha().size();
-    out[3] = (int64_t)es.beta().size();
-    out[4] = es.eigenvalues().size();
-    out[5] = es.eigenvectors().rows();
-    out[6] = es.eigenvectors().cols();
-    out[7] = (int64_t)es.log().size();
-    out[8] = (int64_t)es.info();
-    out[9] = es.hasWARN();
-    out[10] = es.hasERROR();
-  });
-}
-int eigenex_lanczos_solver_get(void* p, double* alpha, double* beta, double* eigenvalues, double* eigenvectors) {
-  return guard([&] {
-    auto& es = static_cast<LanczosBox*>(p)->es;
-    if (alpha) std::copy(es.alpha().begin(), es.alpha().end(), alpha);
-    if (beta) std::copy(es.beta().begin(), es.beta().end(), beta);
-    if (eigenvalues) std::copy(es.eigenvalues().begin(), es.eigenvalues().end(), eigenvalues);
-    if (eigenvectors) std::copy(es.eigenvectors().data(), es.eigenvectors().data() + es.eigenvectors().size(), eigenvectors);
-  });
-}
-int eigenex_lanczos_solver_lanczosvector(void* p, int64_t k, double* out) {
-  return guard([&] {
-    const auto& v = static_cast<LanczosBox*>(p)->es.lanczosvectors();
-    if (k < 0 || k >= (int64_t)v.size()) throw LanczosException("vector index out of range");
-    std::copy(v[(size_t)k].begin(), v[(size_t)k].end(), out);
-  });
-}
-const char* eigenex_lanczos_solver_log_line(void* p, int64_t i) {
-  auto& lg = static_cast<LanczosBox*>(p)->es.log();
-  return (i >= 0 && i < (int64_t)lg.size()) ? lg[(size_t)i].c_str() : "";
-}
-// convergenceLog()[index]: returns its length; copies up to cap entries
-int64_t eigenex_lanczos_solver_convergence_log(void* p, int64_t index, double* out, int64_t cap) {
-  auto& cl = static_cast<LanczosBox*>(p)->es.convergenceLog();
-  auto it = cl.find((Index)index);
-  if (it == cl.end()) return 0;
-  for (int64_t i = 0; i < (int64_t)it->second.size() && i < cap; ++i) out[i] = it->second[(size_t)i];
-  return (int64_t)it->second.size();
-}
+#define EIGENEX_ARNOLDI_FAMILY(PFX, S)                                                                                  \
+  EIGENEX_SOLVER_COMMON(PFX, ArnoldiEigenSolver<S>)                                                                     \
+  int PFX##set(void* p, const char* key, double v, double v_im) { return ar_set<S>(p, key, v, v_im); }                  \
+  int PFX##sizes(void* p, int64_t* out) { return ar_sizes<S>(p, out); }                                                 \
+  int PFX##get(void* p, double* H, double* ev, double* X, double* res) { return ar_get<S>(p, H, ev, X, res); }
 
-// ---- Arnoldi --------------------------------------------------------------------------------
-void* eigenex_arnoldi_solver_create(void) {
-  try {
-    return new ArnoldiBox();
-  } catch (const std::exception& e) {
-    g_serr = e.what();
-    return nullptr;
-  }
-}
-void eigenex_arnoldi_solver_destroy(void* p) { delete static_cast<ArnoldiBox*>(p); }
-int eigenex_arnoldi_solver_set_device_operator(void* p, eigenex_context_t ctx, eigenex_csr_t csr) {
-  return guard([&] {
-    auto* b = static_cast<ArnoldiBox*>(p);
-    b->ctx = device::Context::borrow(ctx);
-    b->op = device::CsrOperator::borrow(b->ctx, csr);
-    b->es.setDeviceOperator(b->op);
-  });
-}
-int eigenex_arnoldi_solver_set_host_operator(void* p, eigenex_context_t ctx, eigenex_matvec_fn fn, void* user, int64_t height) {
-  return guard([&] {
-    auto* b = static_cast<ArnoldiBox*>(p);
-    if (ctx) {
-      b->ctx = device::Context::borrow(ctx);
-      b->es.setDeviceContext(b->ctx);
-    }
-    b->es.setMatrixMultiplication([fn, user](const double* in, double* out) { fn(in, out, user); }, (Index)height);
-  });
-}
-int eigenex_arnoldi_solver_set(void* p, const char* key, double v) {
-  return guard([&] { set_common(static_cast<ArnoldiBox*>(p), key, v); });
-}
-int eigenex_arnoldi_solver_set_indices_for_convergence(void* p, const int64_t* idx, int n) {
-  return guard([&] { static_cast<ArnoldiBox*>(p)->es.setIndicesForConvergence(std::vector<Index>(idx, idx + n)); });
-}
-int eigenex_arnoldi_solver_set_initial_vector(void* p, const double* v, int64_t n) {
-  return guard([&] { static_cast<ArnoldiBox*>(p)->es.setInitialVector(DenseVector<double>(v, (Index)n)); });
-}
-int eigenex_arnoldi_solver_set_orthogonalizing_vectors(void* p, const double* vecs, int64_t n, int count) {
-  return guard([&] {
-    std::vector<DenseVector<double>> q;
-    for (int i = 0; i < count; ++i) q.emplace_back(vecs + (size_t)i * n, (Index)n);
-    static_cast<ArnoldiBox*>(p)->es.setOrthogonalizingVectors(std::move(q));
-  });
-}
-int eigenex_arnoldi_solver_compute(void* p) { return guard([&] { static_cast<ArnoldiBox*>(p)->es.compute(); }); }
-int eigenex_arnoldi_solver_continue(void* p) { return guard([&] { static_cast<ArnoldiBox*>(p)->es.continueToCompute(); }); }
-// sizes: [iterations, nvec, hess_rows, neigenvalues, eigvec_rows, eigvec_cols, nlog, info, hasWARN, hasERROR]
-int eigenex_arnoldi_solver_sizes(void* p, int64_t* out) {
-  return guard([&] {
-    auto& es = static_cast<ArnoldiBox*>(p)->es;
-    out[0] = es.iterations();
-    out[1] = es.arnoldiBase().arnoldivectorsSize();
-    out[2] = es.hessenbergMatrix().rows();
-    out[3] = es.eigenvalues().size();
-    out[4] = es.eigenvectors().rows();
-    out[5] = es.eigenvectors().cols();
-    out[6] = (int64_t)es.log().size();
-    out[7] = (int64_t)es.info();
-    out[8] = es.hasWARN();
-    out[9] = es.hasERROR();
-  });
-}
-// hess: column-major real; eigenvalues / eigenvectors interleaved complex
-int eigenex_arnoldi_solver_get(void* p, double* hess, double* eigenvalues, double* eigenvectors, double* residue) {
-  return guard([&] {
-    auto& es = static_cast<ArnoldiBox*>(p)->es;
-    if (hess) std::copy(es.hessenbergMatrix().data(), es.hessenbergMatrix().data() + es.hessenbergMatrix().size(), hess);
-    if (eigenvalues) std::memcpy(eigenvalues, es.eigenvalues().data(), sizeof(double) * 2 * (size_t)es.eigenvalues().size());
-    if (eigenvectors) std::memcpy(eigenvectors, es.eigenvectors().data(), sizeof(double) * 2 * (size_t)es.eigenvectors().size());
-    if (residue) *residue = es.arnoldiBase().residue();
-  });
-}
-const char* eigenex_arnoldi_solver_log_line(void* p, int64_t i) {
-  auto& lg = static_cast<ArnoldiBox*>(p)->es.log();
-  return (i >= 0 && i < (int64_t)lg.size()) ? lg[(size_t)i].c_str() : "";
-}
+EIGENEX_LANCZOS_FAMILY(eigenex_lanczos_solver_, double)
+EIGENEX_LANCZOS_FAMILY(eigenex_zlanczos_solver_, std::complex<double>)
+EIGENEX_ARNOLDI_FAMILY(eigenex_arnoldi_solver_, double)
+EIGENEX_ARNOLDI_FAMILY(eigenex_zarnoldi_solver_, std::complex<double>)
 
 }  // extern "C"

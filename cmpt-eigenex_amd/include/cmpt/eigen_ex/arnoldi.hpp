@@ -5,9 +5,10 @@
 // eigenproblem on the host; all N-vector work in HIP kernels behind
 // include/eigenex_hip.h.
 //
-// Scalar = double.  The reference's ArnoldiEigenSolver<double> does not compile
-// (arnoldi.hpp:857 assigns a complex to a real); this class
-// implements the evidently intended behaviour: real operator, complex Ritz pairs.
+// Scalar = std::complex<double> (the reference's only working instantiation) or double.
+// The reference's ArnoldiEigenSolver<double> does not compile (arnoldi.hpp:857 assigns a
+// complex to a real); for double this class implements the evidently intended
+// behaviour: real operator, complex Ritz pairs.
 // Two further deliberate clarifications of reference quirks:
 //   * continueToCompute() re-derives the Ritz values from the current Hessenberg
 //     matrix instead of re-using the already shifted and truncated eigenvalues_
@@ -32,7 +33,7 @@ using ArnoldiException = LanczosException;  // reference arnoldi.hpp:45
 // ---------------------------------------------------------------------------
 template <class Scalar_>
 class ArnoldiBase {
-  static_assert(std::is_same<Scalar_, double>::value, "cmpt-eigenex_amd: the device path implements Scalar = double");
+  static_assert(detail::SupportedScalar<Scalar_>::value, "cmpt-eigenex_amd: Scalar must be double or std::complex<double>");
 
  public:
   using Index = EigenEx::Index;
@@ -45,7 +46,7 @@ class ArnoldiBase {
 
   template <class URBG>
   static VectorType makeRandomVector(URBG& g, Index size) {
-    return detail::gaussianUnitVector(g, size);
+    return detail::gaussianUnitVector<Scalar>(g, size);
   }
 
   // ---- settings (reference :113-174) ----
@@ -132,7 +133,7 @@ class ArnoldiBase {
   const std::vector<VectorType>& arnoldivectors() const {
     if (static_cast<Index>(vectorCache_.size()) > nvec_) vectorCache_.resize(static_cast<std::size_t>(nvec_));
     while (static_cast<Index>(vectorCache_.size()) < nvec_)
-      vectorCache_.push_back(dev_.download(EIGENEX_VEC_COL(static_cast<int>(vectorCache_.size()))));
+      vectorCache_.push_back(dev_.template download<Scalar>(EIGENEX_VEC_COL(static_cast<int>(vectorCache_.size()))));
     return vectorCache_;
   }
   Index arnoldivectorsSize() const { return nvec_; }
@@ -151,7 +152,7 @@ class ArnoldiBase {
     matrixMultiplication_ = [](const Scalar*, Scalar*) {};
     matrixHeight_ = 0;
     deviceOperator_.reset();
-    setEigenvalueShift(0.0);
+    setEigenvalueShift(Scalar(0.0));
     setInitialVector();
     setThreshold(DefaultTolerance<RealScalar>::value());
     return *this;
@@ -257,7 +258,7 @@ class ArnoldiBase {
     const Index planned = capacityHint_ > 0 ? capacityHint_ : reserveSize_;
     const Index want = std::max<Index>(std::max<Index>(vectorsNeeded, std::min<Index>(planned, matrixHeight_)), 1);
     if (!dev_.alive() || devHeight_ != matrixHeight_ || devNq_ != nq || devOp_ != deviceOperator_.get()) {
-      dev_.create(contextOrDefault_(), deviceOperator_, matrixHeight_, static_cast<int>(want), nq);
+      dev_.create(contextOrDefault_(), deviceOperator_, matrixHeight_, static_cast<int>(want), nq, detail::IsComplex<Scalar>::value);
       devHeight_ = matrixHeight_;
       devNq_ = nq;
       devOp_ = deviceOperator_.get();
@@ -268,9 +269,10 @@ class ArnoldiBase {
     }
     if (!deviceOperator_) {
       thunk_.fn = matrixMultiplication_;
-      device::check(eigenex_basis_set_host_operator(dev_.handle(), &detail::HostOperatorThunk::call, &thunk_), "eigenex_basis_set_host_operator");
+      device::check(eigenex_basis_set_host_operator(dev_.handle(), &detail::HostOperatorThunk<Scalar>::call, &thunk_), "eigenex_basis_set_host_operator");
     }
-    device::check(eigenex_basis_configure(dev_.handle(), eigenvalueShift_, threshold_, 1, static_cast<int>(ortho_)), "eigenex_basis_configure");
+    const std::complex<double> sh(eigenvalueShift_);
+    device::check(eigenex_basis_configure_z(dev_.handle(), sh.real(), sh.imag(), threshold_, 1, static_cast<int>(ortho_)), "eigenex_basis_configure_z");
     if (orthoDirty_) {
       for (int q = 0; q < nq; ++q) dev_.upload(EIGENEX_VEC_ORTHO(q), orthogonalizingVectors_[static_cast<std::size_t>(q)]);
       orthoDirty_ = false;
@@ -292,8 +294,8 @@ class ArnoldiBase {
     callsEnqueued_ += ncalls;
     eigenex_state_t st;
     devLdh_ = dev_.capacity() + 2;
-    devH_.assign(static_cast<std::size_t>(devLdh_) * static_cast<std::size_t>(dev_.capacity() + 1), 0.0);
-    device::check(eigenex_arnoldi_state(dev_.handle(), &st, devH_.data(), static_cast<int>(devLdh_)), "eigenex_arnoldi_state");
+    devH_.assign(static_cast<std::size_t>(devLdh_) * static_cast<std::size_t>(dev_.capacity() + 1), Scalar(0.0));
+    device::check(eigenex_arnoldi_state(dev_.handle(), &st, reinterpret_cast<double*>(devH_.data()), static_cast<int>(devLdh_)), "eigenex_arnoldi_state");
     devCallsTrue_ = st.calls_true;
     devResidue_ = st.residue;
   }
@@ -307,12 +309,12 @@ class ArnoldiBase {
     h_.resize(static_cast<std::size_t>(i + 1));
     for (Index c = 0; c <= i; ++c) {
       auto& col = h_[static_cast<std::size_t>(c)];
-      col.assign(static_cast<std::size_t>(c + 2), 0.0);
+      col.assign(static_cast<std::size_t>(c + 2), Scalar(0.0));
       for (Index r = 0; r <= c; ++r) col[static_cast<std::size_t>(r)] = devH_[static_cast<std::size_t>(r + c * devLdh_)];
-      col[static_cast<std::size_t>(c + 1)] = c < i ? devH_[static_cast<std::size_t>(c + 1 + c * devLdh_)] : 0.0;
+      col[static_cast<std::size_t>(c + 1)] = c < i ? devH_[static_cast<std::size_t>(c + 1 + c * devLdh_)] : Scalar(0.0);
     }
     // residue after call i: next sub-diagonal entry if a later call has consumed it, else the device's current one
-    residue_ = i + 1 < devCallsTrue_ ? devH_[static_cast<std::size_t>(i + 1 + i * devLdh_)] : devResidue_;
+    residue_ = i + 1 < devCallsTrue_ ? std::real(devH_[static_cast<std::size_t>(i + 1 + i * devLdh_)]) : devResidue_;
     return true;
   }
 
@@ -323,7 +325,7 @@ class ArnoldiBase {
   std::shared_ptr<device::CsrOperator> deviceOperator_;
   std::shared_ptr<device::Context> context_;
   Orthogonalization ortho_ = Orthogonalization::Batched;
-  Scalar eigenvalueShift_ = 0.0;
+  Scalar eigenvalueShift_ = Scalar(0.0);
   Index matrixHeight_ = 0;
   VectorType initialVector_;
   RealScalar threshold_ = 1e-12;
@@ -335,7 +337,7 @@ class ArnoldiBase {
   mutable std::vector<VectorType> vectorCache_;
 
   mutable detail::KrylovDevice dev_;
-  detail::HostOperatorThunk thunk_;
+  detail::HostOperatorThunk<Scalar> thunk_;
   Index devHeight_ = -1;
   int devNq_ = -1;
   const device::CsrOperator* devOp_ = nullptr;
@@ -344,7 +346,7 @@ class ArnoldiBase {
   bool devCreated_ = false;
   bool started_ = false;
   Index callsEnqueued_ = 0, callsRevealed_ = 0, devCallsTrue_ = 0;
-  std::vector<double> devH_;
+  std::vector<Scalar> devH_;
   Index devLdh_ = 0;
   double devResidue_ = 0.0;
 };

@@ -3,6 +3,7 @@
 // is no host fallback for the vector work.
 #pragma once
 
+#include <complex>
 #include <cstdint>
 #include <memory>
 #include <stdexcept>
@@ -78,6 +79,18 @@ class CsrOperator {
               const std::int32_t* rowptr, const std::int32_t* col_global, const double* val)
       : ctx_(std::move(ctx)), n_(n_global) {
     check(eigenex_csr_upload(ctx_->handle(), n_global, row_begin, n_rows, rowptr, col_global, val, &h_), "eigenex_csr_upload");
+  }
+  // complex values (std::complex<double>, crossing the C ABI as interleaved doubles)
+  static std::shared_ptr<CsrOperator> complexCsr(std::shared_ptr<Context> ctx, std::int64_t n_global, std::int64_t row_begin,
+                                                 std::int64_t n_rows, const std::int32_t* rowptr,
+                                                 const std::int32_t* col_global, const std::complex<double>* val) {
+    std::shared_ptr<CsrOperator> op(new CsrOperator());
+    op->ctx_ = std::move(ctx);
+    op->n_ = n_global;
+    check(eigenex_csr_upload_z(op->ctx_->handle(), n_global, row_begin, n_rows, rowptr, col_global,
+                               reinterpret_cast<const double*>(val), &op->h_),
+          "eigenex_csr_upload_z");
+    return op;
   }
   // synthetic 7-point Laplacian on an n^3 grid, generated on the device
   static std::shared_ptr<CsrOperator> laplacian3d(std::shared_ptr<Context> ctx, std::int64_t n) {

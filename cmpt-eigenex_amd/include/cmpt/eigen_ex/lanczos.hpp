@@ -13,7 +13,7 @@
 //     called on the host with host pointers, exactly as in the reference, while the
 //     vector work stays on the GPU (the vector is staged through pinned memory).
 //   * info(): Eigen-style status derived from the same events the reference logs.
-//   * Scalar = double only in this release (complex kernels: see DESIGN.md, out of scope list).
+//   * Scalar = double or std::complex<double> (the two instantiations the reference's samples use).
 //   * VectorType/MatrixType are cmpt::EigenEx::DenseVector/DenseMatrix (dense.hpp),
 //     convertible from/to Eigen types when Eigen is present.
 //   * es_tri() (an Eigen solver object) is replaced by tridiagonalEigenvalues() /
@@ -56,21 +56,46 @@ enum class Orthogonalization {
 
 namespace detail {
 
-// normalised Gaussian vector: reference random.hpp:89-101 with util.hpp:132-148
+template <class S>
+struct IsComplex : std::false_type {};
+template <class R>
+struct IsComplex<std::complex<R>> : std::true_type {};
+
+template <class S>
+struct SupportedScalar : std::integral_constant<bool, std::is_same<S, double>::value || std::is_same<S, std::complex<double>>::value> {};
+
+// one draw per entry for real scalars; real part then imaginary part for complex ones
+// (reference util.hpp:76-97 ComplexNormalDistribution, util.hpp:132-148 NormalDistributionGen)
 template <class URBG>
-inline DenseVector<double> gaussianUnitVector(URBG& g, Index size) {
+inline void drawGaussian(std::normal_distribution<double>& d, URBG& g, double& out) {
+  out = d(g);
+}
+template <class URBG>
+inline void drawGaussian(std::normal_distribution<double>& d, URBG& g, std::complex<double>& out) {
+  const double re = d(g);
+  const double im = d(g);
+  out = std::complex<double>(re, im);
+}
+
+// normalised Gaussian vector: reference random.hpp:89-101
+template <class S, class URBG>
+inline DenseVector<S> gaussianUnitVector(URBG& g, Index size) {
   std::normal_distribution<double> dist;
-  DenseVector<double> v(size < 0 ? 0 : size);
-  for (Index i = 0; i < v.size(); ++i) v[i] = dist(g);
+  DenseVector<S> v(size < 0 ? 0 : size);
+  for (Index i = 0; i < v.size(); ++i) drawGaussian(dist, g, v[i]);
   const double nrm = v.norm();
   if (nrm > 0.0)
     for (Index i = 0; i < v.size(); ++i) v[i] /= nrm;
   return v;
 }
 
+// std::function operator -> C callback; complex data cross the C ABI as interleaved doubles
+template <class S>
 struct HostOperatorThunk {
-  std::function<void(const double*, double*)> fn;
-  static void call(const double* in, double* out, void* user) { static_cast<HostOperatorThunk*>(user)->fn(in, out); }
+  std::function<void(const S*, S*)> fn;
+  static void call(const double* in, double* out, void* user) {
+    static_cast<HostOperatorThunk*>(user)->fn(reinterpret_cast<const S*>(in), reinterpret_cast<S*>(out));
+  }
 };
 
 // Device Krylov state shared by LanczosBase and ArnoldiBase: owns the basis
@@ -86,10 +111,11 @@ class KrylovDevice {
   eigenex_basis_t handle() const { return basis_; }
 
   void create(const std::shared_ptr<device::Context>& ctx, const std::shared_ptr<device::CsrOperator>& op, Index n,
-              int capacity, int n_ortho) {
+              int capacity, int n_ortho, bool is_complex) {
     release();
     ctx_ = ctx;
-    device::check(eigenex_basis_create(ctx->handle(), op ? op->handle() : nullptr, n, capacity, n_ortho, &basis_), "eigenex_basis_create");
+    device::check(eigenex_basis_create_ex(ctx->handle(), op ? op->handle() : nullptr, n, capacity, n_ortho, is_complex ? 1 : 0, &basis_),
+                  "eigenex_basis_create_ex");
     n_global_ = n;
     // rows of host vectors this process sees
     if (ctx->shardsLocal() == ctx->shardsTotal()) {
@@ -111,15 +137,18 @@ class KrylovDevice {
   Index rowBegin() const { return row_begin_; }
   Index localRows() const { return n_rows_; }
   // host vector of global or local length -> pointer to the local rows
-  const double* localSlice(const DenseVector<double>& v) const {
-    if (v.size() == n_rows_) return v.data();
-    if (v.size() == n_global_) return v.data() + row_begin_;
+  template <class S>
+  const double* localSlice(const DenseVector<S>& v) const {
+    if (v.size() == n_rows_) return reinterpret_cast<const double*>(v.data());
+    if (v.size() == n_global_) return reinterpret_cast<const double*>(v.data() + row_begin_);
     throw LanczosException("vector length matches neither the matrix height nor this rank's row count");
   }
-  void upload(int ref, const DenseVector<double>& v) { device::check(eigenex_vec_upload(basis_, ref, localSlice(v)), "eigenex_vec_upload"); }
-  DenseVector<double> download(int ref) const {
-    DenseVector<double> v(n_rows_);
-    device::check(eigenex_vec_download(basis_, ref, v.data()), "eigenex_vec_download");
+  template <class S>
+  void upload(int ref, const DenseVector<S>& v) { device::check(eigenex_vec_upload(basis_, ref, localSlice(v)), "eigenex_vec_upload"); }
+  template <class S>
+  DenseVector<S> download(int ref) const {
+    DenseVector<S> v(n_rows_);
+    device::check(eigenex_vec_download(basis_, ref, reinterpret_cast<double*>(v.data())), "eigenex_vec_download");
     return v;
   }
 
@@ -137,7 +166,7 @@ class KrylovDevice {
 // ---------------------------------------------------------------------------
 template <class Scalar_>
 class LanczosBase {
-  static_assert(std::is_same<Scalar_, double>::value, "cmpt-eigenex_amd: the device path implements Scalar = double");
+  static_assert(detail::SupportedScalar<Scalar_>::value, "cmpt-eigenex_amd: Scalar must be double or std::complex<double>");
 
  public:
   using Index = EigenEx::Index;
@@ -151,7 +180,7 @@ class LanczosBase {
   // random normalised vector, usable as an initial vector (reference :124-135)
   template <class URBG>
   static VectorType makeRandomVector(URBG& g, Index size) {
-    return detail::gaussianUnitVector(g, size);
+    return detail::gaussianUnitVector<Scalar>(g, size);
   }
 
   // ---- settings (reference :161-227) ----
@@ -254,7 +283,7 @@ class LanczosBase {
   const std::vector<VectorType>& lanczosvectors() const {
     if (static_cast<Index>(vectorCache_.size()) > nvec_) vectorCache_.resize(static_cast<std::size_t>(nvec_));
     while (static_cast<Index>(vectorCache_.size()) < nvec_)
-      vectorCache_.push_back(dev_.download(EIGENEX_VEC_COL(static_cast<int>(vectorCache_.size()))));
+      vectorCache_.push_back(dev_.template download<Scalar>(EIGENEX_VEC_COL(static_cast<int>(vectorCache_.size()))));
     return vectorCache_;
   }
   // number of basis vectors without downloading them
@@ -347,7 +376,7 @@ class LanczosBase {
     MatrixType X(dev_.alive() ? dev_.localRows() : matrixHeight_, nev);
     if (nev > 0 && nvec_ > 0)
       device::check(eigenex_ritz_vectors(dev_.handle(), static_cast<int>(nvec_), static_cast<int>(nev), S, static_cast<int>(lds),
-                                         X.data(), X.rows()),
+                                         reinterpret_cast<double*>(X.data()), X.rows()),
                     "eigenex_ritz_vectors");
     return X;
   }
@@ -363,7 +392,7 @@ class LanczosBase {
     const Index planned = capacityHint_ > 0 ? capacityHint_ : reserveSize_;
     const Index want = std::max<Index>(std::max<Index>(vectorsNeeded, std::min<Index>(planned, matrixHeight_ + 1)), 2);
     if (!dev_.alive() || devHeight_ != matrixHeight_ || devNq_ != nq || devOp_ != deviceOperator_.get()) {
-      dev_.create(contextOrDefault_(), deviceOperator_, matrixHeight_, static_cast<int>(want), nq);
+      dev_.create(contextOrDefault_(), deviceOperator_, matrixHeight_, static_cast<int>(want), nq, detail::IsComplex<Scalar>::value);
       devHeight_ = matrixHeight_;
       devNq_ = nq;
       devOp_ = deviceOperator_.get();
@@ -374,7 +403,7 @@ class LanczosBase {
     }
     if (!deviceOperator_) {
       thunk_.fn = matrixMultiplication_;
-      device::check(eigenex_basis_set_host_operator(dev_.handle(), &detail::HostOperatorThunk::call, &thunk_), "eigenex_basis_set_host_operator");
+      device::check(eigenex_basis_set_host_operator(dev_.handle(), &detail::HostOperatorThunk<Scalar>::call, &thunk_), "eigenex_basis_set_host_operator");
     }
     device::check(eigenex_basis_configure(dev_.handle(), eigenvalueShift_, threshold_, reorthogonalizeInterval_, static_cast<int>(ortho_)),
                   "eigenex_basis_configure");
@@ -447,7 +476,7 @@ class LanczosBase {
 
   // device side
   mutable detail::KrylovDevice dev_;
-  detail::HostOperatorThunk thunk_;
+  detail::HostOperatorThunk<Scalar> thunk_;
   Index devHeight_ = -1;
   int devNq_ = -1;
   const device::CsrOperator* devOp_ = nullptr;

@@ -1,7 +1,7 @@
 """ctypes view of libeigenex_solver.so: the flat C wrapper (csrc/solver_capi.cpp) around the
-header-only C++ solver classes LanczosEigenSolver<double> / ArnoldiEigenSolver<double>
-(cmpt-eigenex_amd/include/cmpt/eigen_ex/).  Plumbing for tests/ and bench.py: the Python
-side holds no algorithm, the method names mirror the C++ (= reference) names.
+header-only C++ solver classes LanczosEigenSolver<S> / ArnoldiEigenSolver<S>, S = double or
+std::complex<double> (cmpt-eigenex_amd/include/cmpt/eigen_ex/).  Plumbing for tests/ and
+bench.py: the Python side holds no algorithm, the method names mirror the C++ (= reference) names.
 """
 from __future__ import annotations
 
@@ -20,6 +20,7 @@ _vp = C.c_void_p
 
 UNLIMITED = -1
 INFO = {0: "Success", 1: "NumericalIssue", 2: "NoConvergence", 3: "InvalidInput"}
+FAMILIES = ("lanczos", "zlanczos", "arnoldi", "zarnoldi")
 
 _LIB = None
 
@@ -34,16 +35,17 @@ def lib():
         L.eigenex_solver_last_error.restype = C.c_char_p
         L.eigenex_solver_default_start_vector.argtypes = [C.c_int64, _dp]
         L.eigenex_solver_random_vector.argtypes = [C.c_uint32, C.c_int64, _dp]
+        L.eigenex_solver_random_vector_z.argtypes = [C.c_uint32, C.c_int64, _dp]
         L.eigenex_solver_tridiagonal_eigen.argtypes = [C.c_int, _dp, _dp, _dp, _dp]
         L.eigenex_solver_hessenberg_eigen.argtypes = [C.c_int, _dp, _dp, _dp]
-        for kind in ("lanczos", "arnoldi"):
+        for kind in FAMILIES:
             p = f"eigenex_{kind}_solver_"
             getattr(L, p + "create").restype = _vp
             getattr(L, p + "destroy").argtypes = [_vp]
             getattr(L, p + "destroy").restype = None
             getattr(L, p + "set_device_operator").argtypes = [_vp, _vp, _vp]
             getattr(L, p + "set_host_operator").argtypes = [_vp, _vp, capi.MATVEC_FN, _vp, C.c_int64]
-            getattr(L, p + "set").argtypes = [_vp, C.c_char_p, C.c_double]
+            getattr(L, p + "set").argtypes = [_vp, C.c_char_p, C.c_double, C.c_double]
             getattr(L, p + "set_indices_for_convergence").argtypes = [_vp, _lp, C.c_int]
             getattr(L, p + "set_initial_vector").argtypes = [_vp, _dp, C.c_int64]
             getattr(L, p + "set_orthogonalizing_vectors").argtypes = [_vp, _dp, C.c_int64, C.c_int]
@@ -52,11 +54,14 @@ def lib():
             getattr(L, p + "sizes").argtypes = [_vp, _lp]
             getattr(L, p + "log_line").argtypes = [_vp, C.c_int64]
             getattr(L, p + "log_line").restype = C.c_char_p
-        L.eigenex_lanczos_solver_get.argtypes = [_vp, _dp, _dp, _dp, _dp]
-        L.eigenex_lanczos_solver_lanczosvector.argtypes = [_vp, C.c_int64, _dp]
-        L.eigenex_lanczos_solver_convergence_log.argtypes = [_vp, C.c_int64, _dp, C.c_int64]
-        L.eigenex_lanczos_solver_convergence_log.restype = C.c_int64
-        L.eigenex_arnoldi_solver_get.argtypes = [_vp, _dp, _dp, _dp, _dp]
+        for kind in ("lanczos", "zlanczos"):
+            p = f"eigenex_{kind}_solver_"
+            getattr(L, p + "get").argtypes = [_vp, _dp, _dp, _dp, _dp]
+            getattr(L, p + "lanczosvector").argtypes = [_vp, C.c_int64, _dp]
+            getattr(L, p + "convergence_log").argtypes = [_vp, C.c_int64, _dp, C.c_int64]
+            getattr(L, p + "convergence_log").restype = C.c_int64
+        for kind in ("arnoldi", "zarnoldi"):
+            getattr(L, f"eigenex_{kind}_solver_get").argtypes = [_vp, _dp, _dp, _dp, _dp]
         _LIB = L
     return _LIB
 
@@ -76,7 +81,12 @@ def default_start_vector(n: int) -> np.ndarray:
     return out
 
 
-def random_vector(seed: int, n: int) -> np.ndarray:
+def random_vector(seed: int, n: int, dtype=np.float64) -> np.ndarray:
+    """LanczosBase<S>::makeRandomVector(std::mt19937(seed), n)"""
+    if np.dtype(dtype).kind == "c":
+        out = np.empty(n, np.complex128)
+        _chk(lib().eigenex_solver_random_vector_z(seed, n, _d(out)))
+        return out
     out = np.empty(n)
     _chk(lib().eigenex_solver_random_vector(seed, n, _d(out)))
     return out
@@ -97,15 +107,17 @@ def hessenberg_eigen(H, vectors=True):
     n = H.shape[0]
     vals = np.empty(n, np.complex128)
     vecs = np.empty((n, n), np.complex128, order="F") if vectors else None
-    _chk(lib().eigenex_solver_hessenberg_eigen(n, H.ctypes.data_as(_dp), vals.ctypes.data_as(_dp),
-                                               vecs.ctypes.data_as(_dp) if vectors else None))
+    _chk(lib().eigenex_solver_hessenberg_eigen(n, _d(H), _d(vals), _d(vecs) if vectors else None))
     return vals, vecs
 
 
 class _SolverBase:
-    _kind = ""
+    _base = ""
 
-    def __init__(self):
+    def __init__(self, dtype=np.float64):
+        self.dtype = np.dtype(dtype)
+        self.is_complex = self.dtype.kind == "c"
+        self._kind = ("z" if self.is_complex else "") + self._base
         self._L = lib()
         self.h = _vp(getattr(self._L, f"eigenex_{self._kind}_solver_create")())
         if not self.h:
@@ -116,17 +128,18 @@ class _SolverBase:
         return getattr(self._L, f"eigenex_{self._kind}_solver_{name}")
 
     def setDeviceOperator(self, csr: capi.Csr):
+        assert bool(getattr(csr, "is_complex", False)) == self.is_complex, "scalar type of solver and operator differ"
         self._keep.append(csr)
         _chk(self._f("set_device_operator")(self.h, csr.ctx.h, csr.h))
         return self
 
     def setMatrixMultiplication(self, fn, height: int, ctx: capi.Context | None = None):
         """fn(x: ndarray) -> ndarray, the reference's MatMulFunction (called on the host)."""
-        n = height
+        n, es, dt = height, (2 if self.is_complex else 1), self.dtype
 
         def tramp(pin, pout, _user):
-            x = np.ctypeslib.as_array(pin, shape=(n,))
-            y = np.ctypeslib.as_array(pout, shape=(n,))
+            x = np.ctypeslib.as_array(pin, shape=(n * es,)).view(dt)
+            y = np.ctypeslib.as_array(pout, shape=(n * es,)).view(dt)
             y[:] = fn(x)
 
         cb = capi.MATVEC_FN(tramp)
@@ -140,13 +153,14 @@ class _SolverBase:
                 a = np.ascontiguousarray(v, np.int64)
                 _chk(self._f("set_indices_for_convergence")(self.h, a.ctypes.data_as(_lp), a.size))
             elif k == "initialVector":
-                a = np.ascontiguousarray(v, np.float64)
+                a = np.ascontiguousarray(v, self.dtype)
                 _chk(self._f("set_initial_vector")(self.h, _d(a), a.size))
             elif k == "orthogonalizingVectors":
-                a = np.ascontiguousarray(np.stack(v), np.float64) if len(v) else np.zeros((0, 1))
+                a = np.ascontiguousarray(np.stack(v), self.dtype) if len(v) else np.zeros((0, 1), self.dtype)
                 _chk(self._f("set_orthogonalizing_vectors")(self.h, _d(a), a.shape[1], a.shape[0]))
             else:
-                _chk(self._f("set")(self.h, k.encode(), float(v)))
+                z = complex(v)
+                _chk(self._f("set")(self.h, k.encode(), z.real, z.imag))
         return self
 
     def compute(self):
@@ -174,7 +188,9 @@ class _SolverBase:
 
 
 class LanczosEigenSolver(_SolverBase):
-    _kind = "lanczos"
+    """LanczosEigenSolver<double> (dtype float64) or LanczosEigenSolver<std::complex<double>> (complex128)."""
+
+    _base = "lanczos"
     _names = ("iterations", "nvec", "nalpha", "nbeta", "neig", "vec_rows", "vec_cols", "nlog", "info", "hasWARN", "hasERROR")
 
     def _sizes(self):
@@ -185,24 +201,26 @@ class LanczosEigenSolver(_SolverBase):
     def results(self):
         s = self._sizes()
         alpha, beta, ev = np.zeros(s["nalpha"]), np.zeros(s["nbeta"]), np.zeros(s["neig"])
-        X = np.zeros((s["vec_rows"], s["vec_cols"]), order="F")
-        _chk(self._L.eigenex_lanczos_solver_get(self.h, _d(alpha), _d(beta), _d(ev), _d(X) if X.size else None))
+        X = np.zeros((s["vec_rows"], s["vec_cols"]), self.dtype, order="F")
+        _chk(self._f("get")(self.h, _d(alpha), _d(beta), _d(ev), _d(X) if X.size else None))
         s.update(alpha=alpha, beta=beta, eigenvalues=ev, eigenvectors=X, info_name=INFO[s["info"]])
         return s
 
     def lanczosvector(self, k: int, n_rows: int):
-        out = np.empty(n_rows)
-        _chk(self._L.eigenex_lanczos_solver_lanczosvector(self.h, k, _d(out)))
+        out = np.empty(n_rows, self.dtype)
+        _chk(self._f("lanczosvector")(self.h, k, _d(out)))
         return out
 
     def convergenceLog(self, index: int):
         buf = np.zeros(1 << 16)
-        n = self._L.eigenex_lanczos_solver_convergence_log(self.h, index, _d(buf), buf.size)
+        n = self._f("convergence_log")(self.h, index, _d(buf), buf.size)
         return buf[:n].copy()
 
 
 class ArnoldiEigenSolver(_SolverBase):
-    _kind = "arnoldi"
+    """ArnoldiEigenSolver<double> or ArnoldiEigenSolver<std::complex<double>>."""
+
+    _base = "arnoldi"
     _names = ("iterations", "nvec", "hess_rows", "neig", "vec_rows", "vec_cols", "nlog", "info", "hasWARN", "hasERROR")
 
     def _sizes(self):
@@ -213,11 +231,10 @@ class ArnoldiEigenSolver(_SolverBase):
     def results(self):
         s = self._sizes()
         m = s["hess_rows"]
-        H = np.zeros((m, m), order="F")
+        H = np.zeros((m, m), self.dtype, order="F")
         ev = np.zeros(s["neig"], np.complex128)
         X = np.zeros((s["vec_rows"], s["vec_cols"]), np.complex128, order="F")
         res = C.c_double()
-        _chk(self._L.eigenex_arnoldi_solver_get(self.h, _d(H) if H.size else None, ev.ctypes.data_as(_dp),
-                                                X.ctypes.data_as(_dp) if X.size else None, C.byref(res)))
+        _chk(self._f("get")(self.h, _d(H) if H.size else None, _d(ev), _d(X) if X.size else None, C.byref(res)))
         s.update(hessenberg=H, eigenvalues=ev, eigenvectors=X, residue=res.value, info_name=INFO[s["info"]])
         return s

@@ -326,3 +326,170 @@ def test_arnoldi_sample_property_full_space(mods):
     _assert_same_multiset(D, lam, 1e-10)
     assert es.log()[-3:-1] == ["INFO      arnoldi steps finished with threshold",
                                "INFO      arnoldi steps achieved full of Krylov subspace"]
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference's own samples, in their own scalar type (std::complex<double>)
+# ---------------------------------------------------------------------------------------------
+def _sample2_matrix(n):
+    import scipy.sparse as sp
+
+    i = np.arange(n - 1)
+    rows = np.concatenate([i, i + 1])
+    cols = np.concatenate([i + 1, i])
+    vals = np.concatenate([np.full(n - 1, -1j), np.full(n - 1, 1j)])
+    H = sp.csr_matrix((vals, (rows, cols)), shape=(n, n))
+    H.sort_indices()
+    return H
+
+
+@pytest.mark.parametrize("operator", ["host", "device", "device_sharded"])
+def test_reference_sample_lanczos2_complex(mods, golden_dir, operator):
+    """src/samples/sample_lanczos2.cpp with every setting of the sample (:44-56)."""
+    capi, solver = mods
+    from oracle.stl_random import libstdcxx_normal_vector
+
+    s = json.load(open(os.path.join(golden_dir, "reference_samples.json")))["sample_lanczos2"]
+    n = s["n"]
+    H = _sample2_matrix(n)
+    init = solver.random_vector(s["start_vector_seed_mt19937"], n, np.complex128)  # makeRandomVector(mt19937(1), n)
+    v = libstdcxx_normal_vector(n, np.complex128, seed=1)
+    np.testing.assert_allclose(init, v / np.linalg.norm(v), rtol=0, atol=1e-16)
+
+    def settings(es):
+        es.tolerance, es.min_iterations, es.max_iterations = s["tolerance"], s["min_iterations"], s["max_iterations"]
+        es.max_eigenvalues, es.base.threshold = s["max_eigenvalues"], s["threshold"]
+
+    ref = ko.LanczosEigenSolverOracle(np.complex128)
+    ref.set_matrix_multiplication(lambda x: H @ x, n)
+    ref.base.initial_vector = init
+    settings(ref)
+    ref.compute()
+
+    es = solver.LanczosEigenSolver(np.complex128)
+    ctx = None
+    if operator == "host":
+        es.setMatrixMultiplication(lambda x: H @ x, n)
+    else:
+        ctx = capi.Context(loopback_shards=3) if operator == "device_sharded" else capi.Context()
+        A = capi.Csr.upload(ctx, n, H.indptr, H.indices, H.data)
+        es.setDeviceOperator(A)
+    es.set(eigenvalueShift=0.0, tolerance=s["tolerance"], threshold=s["threshold"], minIterations=s["min_iterations"],
+           maxIterations=s["max_iterations"], computeEigenvectorsOn=1, indicesForConvergence=[0], initialVector=init,
+           maxEigenvalues=s["max_eigenvalues"], orthogonalizingVectors=[], reorthogonalizeInterval=1, reserveSize=128)
+    es.compute()
+    r = es.results()
+    assert es.log() == ref.log
+    assert r["iterations"] == ref.base.iterations and r["nvec"] == len(ref.base.lanczosvectors)
+    assert r["neig"] == 10 and r["eigenvectors"].shape == (n, 10)
+    np.testing.assert_allclose(r["eigenvalues"], ref.eigenvalues, rtol=0, atol=1e-10 * 4.0)
+    assert abs(r["eigenvalues"][0] - s["lowest_ten"][0]) < 1e-4
+    np.testing.assert_allclose(r["alpha"], ref.base.alpha, rtol=0, atol=1e-11)
+    np.testing.assert_allclose(r["beta"], ref.base.beta, rtol=0, atol=1e-11)
+    X = r["eigenvectors"]
+    assert abs(X[0, 0].imag) < 1e-14 and X[0, 0].real > 0
+    assert 1 - abs(np.vdot(X[:, 0], ref.eigenvectors[:, 0])) < 1e-9
+    # run to the full Krylov space: the sample's whole analytic list 2cos(k pi/201) is reproduced
+    es.set(minIterations=n - 1, tolerance=0.0)
+    es.compute()
+    r = es.results()
+    assert r["nvec"] == n
+    np.testing.assert_allclose(r["eigenvalues"], s["lowest_ten"], rtol=0, atol=1e-11)
+    es.close()
+    if ctx:
+        ctx.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_reference_sample_arnoldi_complex(mods, golden_dir, mode):
+    """src/samples/sample_arnoldi.cpp: complex 50x50 matrix, m = 40, two Ritz pairs; A P = P D when m = n."""
+    capi, solver = mods
+    s = json.load(open(os.path.join(golden_dir, "reference_samples.json")))["sample_arnoldi"]
+    n = s["n"]
+    rng = np.random.default_rng(7)
+    A = rng.uniform(-1, 1, (n, n)) + 1j * rng.uniform(-1, 1, (n, n))
+    v0 = solver.random_vector(5489, n, np.complex128)  # the default start vector of the complex instantiation
+    for m, tol in ((s["m"], None), (n, 1e-9)):
+        ref = ko.ArnoldiEigenSolverOracle(np.complex128)
+        ref.set_matrix_multiplication(lambda x: A @ x, n)
+        ref.base.initial_vector = v0
+        ref.min_iterations = ref.max_iterations = m
+        ref.tolerance, ref.max_eigenvalues = s["tolerance"], s["max_eigenvalues"]
+        ref.compute()
+        es = solver.ArnoldiEigenSolver(np.complex128)
+        es.setMatrixMultiplication(lambda x: A @ x, n)
+        es.set(minIterations=m, maxIterations=m, tolerance=s["tolerance"], maxEigenvalues=s["max_eigenvalues"],
+               initialVector=v0, orthogonalization=mode)
+        es.compute()
+        r = es.results()
+        assert es.log() == ref.log
+        assert (r["iterations"], r["nvec"]) == (m, m)
+        np.testing.assert_allclose(r["hessenberg"], ref.hessenberg_matrix, rtol=0, atol=1e-11)
+        _assert_same_multiset(r["eigenvalues"], ref.eigenvalues, 1e-10 * np.abs(ref.eigenvalues).max())
+        P, D = r["eigenvectors"], r["eigenvalues"]
+        assert P.shape == (n, 2)
+        res = np.abs(A @ P - P * D).max()
+        res_ref = np.abs(A @ ref.eigenvectors - ref.eigenvectors * ref.eigenvalues).max()
+        assert abs(res - res_ref) < 1e-8
+        if tol:
+            assert res < tol
+        for e in range(2):
+            k = int(np.argmin(np.abs(ref.eigenvalues - D[e])))
+            assert 1 - abs(np.vdot(P[:, e], ref.eigenvectors[:, k])) < 1e-8
+            assert abs(P[0, e].imag) < 1e-13 and P[0, e].real > 0
+        es.close()
+
+
+def test_complex_arnoldi_device_operator_with_shift(mods):
+    capi, solver = mods
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(31)
+    n, m = 2500, 35
+    G = sp.random(n, n, density=8 / n, random_state=np.random.RandomState(3), format="csr")
+    G = sp.csr_matrix((G.data + 1j * rng.standard_normal(G.data.size), G.indices, G.indptr), shape=(n, n))
+    G.sort_indices()
+    v0 = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    shift = 0.4 - 0.25j
+    ref = ko.ArnoldiEigenSolverOracle(np.complex128)
+    ref.set_matrix_multiplication(lambda x: G @ x, n)
+    ref.base.initial_vector = v0
+    ref.base.eigenvalue_shift = shift
+    ref.min_iterations = ref.max_iterations = m
+    ref.max_eigenvalues = 4
+    ref.compute()
+    ctx = capi.Context(loopback_shards=2)
+    A = capi.Csr.upload(ctx, n, G.indptr, G.indices, G.data)
+    es = solver.ArnoldiEigenSolver(np.complex128)
+    es.setDeviceOperator(A).set(minIterations=m, maxIterations=m, maxEigenvalues=4, initialVector=v0, eigenvalueShift=shift)
+    es.compute()
+    r = es.results()
+    assert es.log() == ref.log
+    np.testing.assert_allclose(r["hessenberg"], ref.hessenberg_matrix, rtol=0, atol=1e-10)
+    _assert_same_multiset(r["eigenvalues"], ref.eigenvalues, 1e-10 * np.abs(ref.eigenvalues).max())
+    for e in range(4):
+        k = int(np.argmin(np.abs(ref.eigenvalues - r["eigenvalues"][e])))
+        assert 1 - abs(np.vdot(r["eigenvectors"][:, e], ref.eigenvectors[:, k])) < 1e-8
+    ctx.close()
+
+
+def test_cpp_program_reference_sample_lanczos2_complex(golden_dir, tmp_path):
+    """The reference's complex sample as a compiled C++ user program on the header-only API."""
+    exe = str(tmp_path / "sample2_amd")
+    lib = os.path.join(ROOT, "cmpt-eigenex_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-I", os.path.join(ROOT, "include"), "-I",
+                           os.path.join(ROOT, "cmpt-eigenex_amd", "include"),
+                           os.path.join(ROOT, "tests", "cpp", "sample_lanczos2_amd.cpp"), "-o", exe, "-L", lib,
+                           "-leigenex_hip", "-Wl,-rpath," + lib])
+    out = json.loads(subprocess.check_output([exe]).decode())
+    gold = json.load(open(os.path.join(golden_dir, "reference_samples.json")))["sample_lanczos2"]
+    for key in ("host_operator", "device_operator"):
+        o = out[key]
+        assert o["matrix_height"] == 200 and len(o["eigenvalues"]) == 10 and o["hasWARN"] == 0
+        assert o["subspace_rank"] == o["iterations"] + 1
+        assert abs(o["eigenvalues"][0] - gold["lowest_ten"][0]) < 1e-4  # stopping rule 1e-7 on the step-to-step change
+        assert o["residual0"] < 1e-2
+        assert abs(o["x00"][1]) < 1e-14 and o["x00"][0] > 0  # phase fix: first entry real positive
+        assert o["log"][-2] == "INFO      lanczos steps converged with tolerance"
+    assert out["host_operator"]["iterations"] == out["device_operator"]["iterations"]
+    np.testing.assert_allclose(out["host_operator"]["eigenvalues"], out["device_operator"]["eigenvalues"], rtol=0, atol=1e-10)
