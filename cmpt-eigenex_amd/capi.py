@@ -83,6 +83,7 @@ SIGNATURES = {
     "eigenex_vec_copy": (C.c_int, [_vp, C.c_int, C.c_int]),
     "eigenex_basis_reserve": (C.c_int, [_vp, C.c_int]),
     "eigenex_basis_capacity": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "eigenex_basis_tune": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),
     "eigenex_ritz_vectors_complex": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, C.c_int, _dp, C.c_int64]),
     "eigenex_apply": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, _dp]),
     "eigenex_dots": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
@@ -286,6 +287,9 @@ class Basis:
 
         self._cb = MATVEC_FN(tramp)
         _chk(lib().eigenex_basis_set_host_operator(self.h, self._cb, None))
+
+    def tune(self, vec_blocks_per_cu=2, spmv_blocks_per_cu=4, spmv_xcd_aware=0):
+        _chk(lib().eigenex_basis_tune(self.h, vec_blocks_per_cu, spmv_blocks_per_cu, spmv_xcd_aware))
 
     def clear(self):
         _chk(lib().eigenex_basis_clear(self.h))

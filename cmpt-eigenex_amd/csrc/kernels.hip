@@ -15,6 +15,8 @@
 // re-reads are served by L2 / Infinity Cache.
 #include "kernels.hpp"
 
+#include <cstdlib>
+
 namespace eigenex {
 
 namespace {
@@ -48,18 +50,20 @@ __device__ __forceinline__ const double* column_ptr(const ColumnSet& cs, int ci)
 // dots kernel and the update kernel produce bit-identical w0.
 template <bool FULL>
 __device__ __forceinline__ void load_w0(double2 (&w)[4], const double* src, const ThreeTerm& tt,
-                                        double a, double b, int64_t base, int64_t n) {
+                                        double a, double b, int64_t base, int64_t n, double2 (*keep_uk)[4] = nullptr,
+                                        double2 (*keep_ukm1)[4] = nullptr) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int64_t row = base + i * (2 * kBlock);
+    double2 u = make_double2(0.0, 0.0), um = make_double2(0.0, 0.0);
     if (FULL || row < n) {
       double2 s = ld2(src + row);
       if (tt.uk) {
-        const double2 u = ld2(tt.uk + row);
+        u = ld2(tt.uk + row);
         s.x = fma(-a, u.x, s.x);
         s.y = fma(-a, u.y, s.y);
         if (tt.ukm1) {
-          const double2 um = ld2(tt.ukm1 + row);
+          um = ld2(tt.ukm1 + row);
           s.x = fma(-b, um.x, s.x);
           s.y = fma(-b, um.y, s.y);
         }
@@ -68,7 +72,20 @@ __device__ __forceinline__ void load_w0(double2 (&w)[4], const double* src, cons
     } else {
       w[i] = make_double2(0.0, 0.0);
     }
+    if (keep_uk) (*keep_uk)[i] = u;
+    if (keep_ukm1) (*keep_ukm1)[i] = um;
   }
+}
+
+// The three-term vectors u_k, u_{k-1} are also the last two basis columns of a full
+// re-orthogonalisation pass (columns 0..k): their tiles are taken from the registers / caches that
+// formed w0 instead of being streamed from HBM a second time (2 of j+3 column reads per pass).
+__device__ __forceinline__ int tail_columns(const ThreeTerm& tt, const ColumnSet& cs) {
+  if (!tt.uk || cs.stride != 1 || cs.count < 1) return 0;
+  const double* last = cs.V + (int64_t)(cs.first + cs.count - 1) * cs.ldv;
+  if (last != tt.uk) return 0;
+  if (tt.ukm1 && cs.count >= 2 && tt.ukm1 == last - cs.ldv) return 2;
+  return 1;
 }
 
 template <bool FULL>
@@ -102,25 +119,58 @@ __device__ __forceinline__ void dotc8(const double2 (&w)[4], const double2 (&x)[
   }
 }
 
-template <bool FULL, bool CPLX>
+// Sums four per-lane values (one per column) over the wave with 7 shuffle+add steps instead of
+// 4 x 6: halves are swapped pairwise (offsets 32, 16) so that afterwards the 16-lane group g holds
+// column g, then a 4-step butterfly inside the group.  Every lane of group g returns column g's sum.
+__device__ __forceinline__ double wave_sum4(double s0, double s1, double s2, double s3, int lane) {
+  const bool up = (lane & 32) != 0;
+  double keep0 = up ? s2 : s0, keep1 = up ? s3 : s1;
+  const double send0 = up ? s0 : s2, send1 = up ? s1 : s3;
+  keep0 += __shfl_xor(send0, 32, 64);
+  keep1 += __shfl_xor(send1, 32, 64);
+  const bool up2 = (lane & 16) != 0;
+  double k = up2 ? keep1 : keep0;
+  const double snd = up2 ? keep0 : keep1;
+  k += __shfl_xor(snd, 16, 64);
+  k += __shfl_xor(k, 8, 64);
+  k += __shfl_xor(k, 4, 64);
+  k += __shfl_xor(k, 2, 64);
+  k += __shfl_xor(k, 1, 64);
+  return k;
+}
+
+template <bool FULL, bool CPLX, bool RED4>
 __device__ __forceinline__ void dots_tile(const double* __restrict__ src, const ThreeTerm& tt, double a, double b,
                                           const ColumnSet& cs, int ncols, int64_t base, int64_t n, double* wave_acc) {
   constexpr int ES = CPLX ? 2 : 1;
   const int lane = threadIdx.x & 63;
   double2 w[4];
   load_w0<FULL>(w, src, tt, a, b, base, n);
-  int ci = 0;
-  for (; ci + 4 <= ncols; ci += 4) {
+  // columns are visited from the last one down: with full re-orthogonalisation the first group then
+  // contains u_k and u_{k-1}, whose tiles load_w0 has just pulled through L1/L2 (no second HBM read);
+  // every h_c is an independent sum, so the order does not touch the results.
+  const int rem = ncols & 3;
+  for (int ci = ncols - 4; ci >= 0; ci -= 4) {
     double2 x0[4], x1[4], x2[4], x3[4];
-    load_col<FULL>(x0, column_ptr(cs, ci + 0), base, n);
-    load_col<FULL>(x1, column_ptr(cs, ci + 1), base, n);
-    load_col<FULL>(x2, column_ptr(cs, ci + 2), base, n);
     load_col<FULL>(x3, column_ptr(cs, ci + 3), base, n);
+    load_col<FULL>(x2, column_ptr(cs, ci + 2), base, n);
+    load_col<FULL>(x1, column_ptr(cs, ci + 1), base, n);
+    load_col<FULL>(x0, column_ptr(cs, ci + 0), base, n);
     double r0, r1, r2, r3, i0, i1, i2, i3;
     dotc8<CPLX>(w, x0, r0, i0);
     dotc8<CPLX>(w, x1, r1, i1);
     dotc8<CPLX>(w, x2, r2, i2);
     dotc8<CPLX>(w, x3, r3, i3);
+    if (RED4) {
+      const double kr = wave_sum4(r0, r1, r2, r3, lane);
+      double ki = 0.0;
+      if (CPLX) ki = wave_sum4(i0, i1, i2, i3, lane);
+      if ((lane & 15) == 0) {
+        wave_acc[ES * (ci + (lane >> 4))] += kr;
+        if (CPLX) wave_acc[ES * (ci + (lane >> 4)) + 1] += ki;
+      }
+      continue;
+    }
     r0 = wave_sum(r0);
     r1 = wave_sum(r1);
     r2 = wave_sum(r2);
@@ -144,7 +194,7 @@ __device__ __forceinline__ void dots_tile(const double* __restrict__ src, const 
       }
     }
   }
-  for (; ci < ncols; ++ci) {
+  for (int ci = rem - 1; ci >= 0; --ci) {
     double2 x0[4];
     load_col<FULL>(x0, column_ptr(cs, ci), base, n);
     double r0, i0;
@@ -159,7 +209,7 @@ __device__ __forceinline__ void dots_tile(const double* __restrict__ src, const 
 }
 
 // partials[(ES*c + part)*pstride + block]
-template <bool CPLX>
+template <bool CPLX, bool RED4>
 __global__ __launch_bounds__(kBlock) void k_dots(const double* __restrict__ src, ThreeTerm tt, ColumnSet cs,
                                                  int64_t n, int64_t ntiles, double* __restrict__ partials,
                                                  int pstride, const Ctrl* __restrict__ ctrl) {
@@ -177,9 +227,9 @@ __global__ __launch_bounds__(kBlock) void k_dots(const double* __restrict__ src,
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t base = tile * kTileRows + 2 * threadIdx.x;
     if ((tile + 1) * kTileRows <= n)
-      dots_tile<true, CPLX>(src, tt, a, b, cs, ncols, base, n, wave_acc);
+      dots_tile<true, CPLX, RED4>(src, tt, a, b, cs, ncols, base, n, wave_acc);
     else
-      dots_tile<false, CPLX>(src, tt, a, b, cs, ncols, base, n, wave_acc);
+      dots_tile<false, CPLX, RED4>(src, tt, a, b, cs, ncols, base, n, wave_acc);
   }
   __syncthreads();
   for (int c = threadIdx.x; c < nacc; c += kBlock)
@@ -212,26 +262,36 @@ __device__ __forceinline__ void axmy8(double2 (&w)[4], const double* __restrict_
 template <bool FULL, bool CPLX>
 __device__ __forceinline__ double update_tile(const double* src, double* dst,  // may alias (in-place update)
                                               const ThreeTerm& tt, double a, double b, const ColumnSet& cs, int ncols,
-                                              const double* __restrict__ h, int64_t base, int64_t n) {
-  double2 w[4];
-  load_w0<FULL>(w, src, tt, a, b, base, n);
-  int ci = 0;
-  for (; ci + 4 <= ncols; ci += 4) {
-    double2 x0[4], x1[4], x2[4], x3[4];
-    load_col<FULL>(x0, column_ptr(cs, ci + 0), base, n);
-    load_col<FULL>(x1, column_ptr(cs, ci + 1), base, n);
-    load_col<FULL>(x2, column_ptr(cs, ci + 2), base, n);
-    load_col<FULL>(x3, column_ptr(cs, ci + 3), base, n);
-    axmy8<CPLX>(w, h, ci + 0, x0);
-    axmy8<CPLX>(w, h, ci + 1, x1);
-    axmy8<CPLX>(w, h, ci + 2, x2);
-    axmy8<CPLX>(w, h, ci + 3, x3);
-  }
-  for (; ci < ncols; ++ci) {
-    double2 x0[4];
-    load_col<FULL>(x0, column_ptr(cs, ci), base, n);
-    axmy8<CPLX>(w, h, ci, x0);
-  }
+                                              int ntail, const double* __restrict__ h, int64_t base, int64_t n) {
+  double2 w[4], uk[4], ukm1[4];
+  load_w0<FULL>(w, src, tt, a, b, base, n, &uk, &ukm1);
+  // basis columns [0, nv) stream from HBM; the last `ntail` basis columns are u_{k-1}, u_k, still in
+  // registers from the three-term recurrence; then the orthogonalizing vectors.  Subtraction order
+  // stays c ascending, as in the reference.
+  const int nv = cs.count - ntail;
+  auto from_memory = [&](int lo, int hi) {
+    int ci = lo;
+    for (; ci + 4 <= hi; ci += 4) {
+      double2 x0[4], x1[4], x2[4], x3[4];
+      load_col<FULL>(x0, column_ptr(cs, ci + 0), base, n);
+      load_col<FULL>(x1, column_ptr(cs, ci + 1), base, n);
+      load_col<FULL>(x2, column_ptr(cs, ci + 2), base, n);
+      load_col<FULL>(x3, column_ptr(cs, ci + 3), base, n);
+      axmy8<CPLX>(w, h, ci + 0, x0);
+      axmy8<CPLX>(w, h, ci + 1, x1);
+      axmy8<CPLX>(w, h, ci + 2, x2);
+      axmy8<CPLX>(w, h, ci + 3, x3);
+    }
+    for (; ci < hi; ++ci) {
+      double2 x0[4];
+      load_col<FULL>(x0, column_ptr(cs, ci), base, n);
+      axmy8<CPLX>(w, h, ci, x0);
+    }
+  };
+  from_memory(0, nv);
+  if (ntail == 2) axmy8<CPLX>(w, h, cs.count - 2, ukm1);
+  if (ntail >= 1) axmy8<CPLX>(w, h, cs.count - 1, uk);
+  from_memory(cs.count, ncols);
   double nrm = 0.0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -254,13 +314,14 @@ __global__ __launch_bounds__(kBlock) void k_update(const double* src, double* ds
   const int ncols = cs.count + cs.nq;
   const double a = tt.uk ? *tt.a : 0.0;
   const double b = (tt.uk && tt.ukm1) ? *tt.b : 0.0;
+  const int ntail = tail_columns(tt, cs);
   double nrm = 0.0;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t base = tile * kTileRows + 2 * threadIdx.x;
     if ((tile + 1) * kTileRows <= n)
-      nrm += update_tile<true, CPLX>(src, dst, tt, a, b, cs, ncols, h, base, n);
+      nrm += update_tile<true, CPLX>(src, dst, tt, a, b, cs, ncols, ntail, h, base, n);
     else
-      nrm += update_tile<false, CPLX>(src, dst, tt, a, b, cs, ncols, h, base, n);
+      nrm += update_tile<false, CPLX>(src, dst, tt, a, b, cs, ncols, ntail, h, base, n);
   }
   nrm = block_sum(nrm, lds4);
   if (threadIdx.x == 0) partials[blockIdx.x] = nrm;
@@ -293,11 +354,28 @@ __global__ __launch_bounds__(kBlock) void k_reduce(const double* __restrict__ pa
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int skew(int i) { return i + (i >> 5); }
 
+// Tile schedule of a persistent SpMV workgroup.  Plain: tiles b, b+G, ...  XCD-aware (T1 of the CDNA
+// guide): workgroups b and b+8 share an XCD (round-robin dispatch), so XCD x = b%8 walks its own
+// contiguous eighth of the tiles with its G/8 workgroups; neighbouring rows' operator-input lines are
+// then fetched into one L2 instead of eight.  Placement only changes speed, never results.
+struct TileRange {
+  int64_t first, step, end;
+};
+__device__ __forceinline__ TileRange spmv_tiles(int64_t ntiles, int xcd_aware) {
+  const int64_t G = gridDim.x, b = blockIdx.x;
+  if (xcd_aware && (G & 7) == 0) {
+    const int64_t chunk = (ntiles + 7) >> 3, x = b & 7, j = b >> 3;
+    const int64_t lo = x * chunk, hi = lo + chunk < ntiles ? lo + chunk : ntiles;
+    return TileRange{lo + j, G >> 3, hi};
+  }
+  return TileRange{b, G, ntiles};
+}
+
 __global__ __launch_bounds__(kBlock) void k_spmv(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                  const double* __restrict__ val, const double* __restrict__ x_ext,
                                                  const double* __restrict__ scale_ptr, double shift,
                                                  double* __restrict__ y, double* __restrict__ u_out, int64_t n,
-                                                 int64_t ntiles, double* __restrict__ partials,
+                                                 int64_t ntiles, double* __restrict__ partials, int xcd_aware,
                                                  const Ctrl* __restrict__ ctrl) {
   __shared__ double prod[kSpmvChunk + kSpmvChunk / 32 + 8];
   __shared__ double lds4[4];
@@ -305,7 +383,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int32_t* __restrict__ row
   const double scale = scale_ptr ? *scale_ptr : 1.0;
   const int tid = threadIdx.x;
   double dot = 0.0;
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const TileRange tr = spmv_tiles(ntiles, xcd_aware);
+  for (int64_t tile = tr.first; tile < tr.end; tile += tr.step) {
     const int64_t r0 = tile * kSpmvRows;
     const int64_t r = r0 + tid;
     int rs = 0, re = 0;
@@ -379,7 +458,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_z(const int32_t* __restrict__ r
                                                    const double* __restrict__ scale_ptr, double shift_re,
                                                    double shift_im, double2* __restrict__ y,
                                                    double2* __restrict__ u_out, int64_t n, int64_t ntiles,
-                                                   double* __restrict__ partials, int pstride,
+                                                   double* __restrict__ partials, int pstride, int xcd_aware,
                                                    const Ctrl* __restrict__ ctrl) {
   __shared__ double2 prod[kSpmvChunkZ + kSpmvChunkZ / 16 + 8];
   __shared__ double lds4[4];
@@ -388,7 +467,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv_z(const int32_t* __restrict__ r
   const int tid = threadIdx.x;
   const bool has_shift = shift_re != 0.0 || shift_im != 0.0;
   double dr = 0.0, di = 0.0;
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const TileRange tr = spmv_tiles(ntiles, xcd_aware);
+  for (int64_t tile = tr.first; tile < tr.end; tile += tr.step) {
     const int64_t r0 = tile * kSpmvRows;
     const int64_t r = r0 + tid;
     int rs = 0, re = 0;
@@ -776,10 +856,21 @@ void launch_dots(hipStream_t s, const double* src, ThreeTerm tt, ColumnSet cs, i
   if (ncols <= 0) return;
   const int64_t ntiles = (n + kTileRows - 1) / kTileRows;
   const size_t shmem = (size_t)4 * ncols * (cplx ? 2 : 1) * sizeof(double);
-  if (cplx)
-    hipLaunchKernelGGL(k_dots<true>, dim3(grid), dim3(kBlock), shmem, s, src, tt, cs, n, ntiles, partials, pstride, ctrl);
-  else
-    hipLaunchKernelGGL(k_dots<false>, dim3(grid), dim3(kBlock), shmem, s, src, tt, cs, n, ntiles, partials, pstride, ctrl);
+  static const bool red4 = [] {
+    const char* e = getenv("EIGENEX_DOTS_RED4");
+    return e ? atoi(e) != 0 : true;
+  }();
+  if (cplx) {
+    if (red4)
+      hipLaunchKernelGGL((k_dots<true, true>), dim3(grid), dim3(kBlock), shmem, s, src, tt, cs, n, ntiles, partials, pstride, ctrl);
+    else
+      hipLaunchKernelGGL((k_dots<true, false>), dim3(grid), dim3(kBlock), shmem, s, src, tt, cs, n, ntiles, partials, pstride, ctrl);
+  } else {
+    if (red4)
+      hipLaunchKernelGGL((k_dots<false, true>), dim3(grid), dim3(kBlock), shmem, s, src, tt, cs, n, ntiles, partials, pstride, ctrl);
+    else
+      hipLaunchKernelGGL((k_dots<false, false>), dim3(grid), dim3(kBlock), shmem, s, src, tt, cs, n, ntiles, partials, pstride, ctrl);
+  }
 }
 
 void launch_update(hipStream_t s, const double* src, double* dst, ThreeTerm tt, ColumnSet cs, const double* h,
@@ -793,11 +884,11 @@ void launch_update(hipStream_t s, const double* src, double* dst, ThreeTerm tt, 
 
 void launch_spmv_z(hipStream_t s, const int32_t* rowptr, const int32_t* col, const double* val, const double* x_ext,
                    const double* scale, double shift_re, double shift_im, double* y, double* u_out, int64_t n,
-                   double* partials, int pstride, int grid, const Ctrl* ctrl) {
+                   double* partials, int pstride, int grid, const Ctrl* ctrl, int xcd_aware) {
   const int64_t ntiles = (n + kSpmvRows - 1) / kSpmvRows;
   hipLaunchKernelGGL(k_spmv_z, dim3(grid), dim3(kBlock), 0, s, rowptr, col, reinterpret_cast<const double2*>(val),
                      reinterpret_cast<const double2*>(x_ext), scale, shift_re, shift_im, reinterpret_cast<double2*>(y),
-                     reinterpret_cast<double2*>(u_out), n, ntiles, partials, pstride, ctrl);
+                     reinterpret_cast<double2*>(u_out), n, ntiles, partials, pstride, xcd_aware, ctrl);
 }
 
 void launch_shift_dot_z(hipStream_t s, double* y, const double* u, double shift_re, double shift_im, int64_t n,
@@ -814,10 +905,10 @@ void launch_reduce(hipStream_t s, const double* partials, int pstride, int nbloc
 
 void launch_spmv(hipStream_t s, const int32_t* rowptr, const int32_t* col, const double* val, const double* x_ext,
                  const double* scale, double shift, double* y, double* u_out, int64_t n, double* partials, int grid,
-                 const Ctrl* ctrl) {
+                 const Ctrl* ctrl, int xcd_aware) {
   const int64_t ntiles = (n + kSpmvRows - 1) / kSpmvRows;
   hipLaunchKernelGGL(k_spmv, dim3(grid), dim3(kBlock), 0, s, rowptr, col, val, x_ext, scale, shift, y, u_out, n,
-                     ntiles, partials, ctrl);
+                     ntiles, partials, xcd_aware, ctrl);
 }
 
 void launch_scale(hipStream_t s, const double* x, const double* scale_dev, double scale_host, double* out, int64_t n,

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -49,6 +50,11 @@ int fail(int code, const std::string& msg) {
   } while (0)
 
 inline int64_t pad_rows(int64_t n) { return (n + 63) / 64 * 64; }
+
+// persistent-grid sizes: workgroups per CU for the slab kernels (dots/update) and for the SpMV
+constexpr int kDefaultVecBlocksPerCu = 2;   // in-process A/B at 128^3..512^3: 2 beats 4 by 1-2 % (profiles/)
+constexpr int kDefaultSpmvBlocksPerCu = 4;  // 4 beats 8 by 9 % on the 7-point stencil
+constexpr int kMaxBlocksPerCu = 16;
 
 inline void partition(int64_t n, int P, int s, int64_t* b, int64_t* e) {
   *b = (int64_t)((__int128)n * s / P);
@@ -180,7 +186,7 @@ struct BasisShard {
   double* X = nullptr;  // Ritz vector scratch (ldv x 8), lazy
   Ctrl* ctrl = nullptr;
   Ctrl* ctrl_zero = nullptr;  // always-zero control block for the stand-alone primitives
-  int g_vec = 1, g_spmv = 1, pstride = 1;
+  int g_vec = 1, g_spmv = 1, pstride = 1, xcd_aware = 0;  // XCD-contiguous SpMV tiles measured 7 % slower at 512^3
 };
 
 }  // namespace
@@ -548,10 +554,10 @@ int enq_apply(eigenex_basis_s* b, int ucol, bool want_dot) {
         ProfScope ps(c, EIGENEX_K_SPMV, (4.0 + 8.0 * b->es) * m->nnz + 4.0 * (m->nloc + 1) + 32.0 * s.nd + (want_dot ? 16.0 * s.nd : 0.0));
         if (b->es == 2)
           launch_spmv_z(c->stream, m->rowptr, m->col, m->val, s.w, &s.ctrl->scale, b->shift, b->shift_im, s.v,
-                        s.V + (int64_t)ucol * s.ldd, s.nloc, want_dot ? s.partials : nullptr, s.pstride, s.g_spmv, s.ctrl);
+                        s.V + (int64_t)ucol * s.ldd, s.nloc, want_dot ? s.partials : nullptr, s.pstride, s.g_spmv, s.ctrl, s.xcd_aware);
         else
           launch_spmv(c->stream, m->rowptr, m->col, m->val, s.w, &s.ctrl->scale, b->shift, s.v,
-                      s.V + (int64_t)ucol * s.ldd, s.nloc, want_dot ? s.partials : nullptr, s.g_spmv, s.ctrl);
+                      s.V + (int64_t)ucol * s.ldd, s.nloc, want_dot ? s.partials : nullptr, s.g_spmv, s.ctrl, s.xcd_aware);
       }
       if (want_dot) {
         ProfScope ps(c, EIGENEX_K_SMALL, 0.0);
@@ -1097,9 +1103,11 @@ int eigenex_basis_create_ex(eigenex_context_t c, eigenex_csr_t csr, int64_t n_gl
       HIPCHK(hipMemsetAsync(s.start, 0, vbytes, c->stream));
       HIPCHK(hipMalloc(&s.w, sizeof(double) * (size_t)(s.ldv + s.nhalo + 8) * s.es));
       HIPCHK(hipMemsetAsync(s.w, 0, sizeof(double) * (size_t)(s.ldv + s.nhalo + 8) * s.es, c->stream));
-      s.g_vec = grid_for_tiles((s.nd + kTileRows - 1) / kTileRows, 4);
-      s.g_spmv = grid_for_tiles((s.nloc + kSpmvRows - 1) / kSpmvRows, 8);
-      s.pstride = std::max(s.g_vec, s.g_spmv);
+      s.g_vec = grid_for_tiles((s.nd + kTileRows - 1) / kTileRows, kDefaultVecBlocksPerCu);
+      s.g_spmv = grid_for_tiles((s.nloc + kSpmvRows - 1) / kSpmvRows, kDefaultSpmvBlocksPerCu);
+      // room for eigenex_basis_tune up to kMaxBlocksPerCu workgroups per CU
+      s.pstride = std::max(grid_for_tiles((s.nd + kTileRows - 1) / kTileRows, kMaxBlocksPerCu),
+                           grid_for_tiles((s.nloc + kSpmvRows - 1) / kSpmvRows, kMaxBlocksPerCu));
       const int rows = 2 * std::max(b->maxcols, 8) + 4;
       HIPCHK(hipMalloc(&s.partials, sizeof(double) * (size_t)s.pstride * rows));
       HIPCHK(hipMalloc(&s.hbuf, sizeof(double) * (2 * b->maxcols + 40)));
@@ -1131,6 +1139,17 @@ int eigenex_basis_create_ex(eigenex_context_t c, eigenex_csr_t csr, int64_t n_gl
     return rc;
   }
   *out = b;
+  return 0;
+}
+
+int eigenex_basis_tune(eigenex_basis_t b, int vec_blocks_per_cu, int spmv_blocks_per_cu, int spmv_xcd_aware) {
+  if (!b || vec_blocks_per_cu < 1 || vec_blocks_per_cu > kMaxBlocksPerCu || spmv_blocks_per_cu < 1 || spmv_blocks_per_cu > kMaxBlocksPerCu)
+    return fail(EIGENEX_ERR_ARG, "eigenex_basis_tune: blocks per CU must be in [1, 16]");
+  for (auto& s : b->sh) {
+    s.g_vec = grid_for_tiles((s.nd + kTileRows - 1) / kTileRows, vec_blocks_per_cu);
+    s.g_spmv = grid_for_tiles((s.nloc + kSpmvRows - 1) / kSpmvRows, spmv_blocks_per_cu);
+    s.xcd_aware = spmv_xcd_aware != 0;
+  }
   return 0;
 }
 
