@@ -384,36 +384,64 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int32_t* __restrict__ row
   const int tid = threadIdx.x;
   double dot = 0.0;
   const TileRange tr = spmv_tiles(ntiles, xcd_aware);
-  for (int64_t tile = tr.first; tile < tr.end; tile += tr.step) {
-    const int64_t r0 = tile * kSpmvRows;
-    const int64_t r = r0 + tid;
-    int rs = 0, re = 0;
+  // row pointers of a tile: fetched one tile ahead, so that their latency is not part of the chain
+  // rowptr -> val/col -> x that every tile otherwise pays in sequence
+  auto tile_rows = [&](int64_t tile, int& rs, int& re, int& p0, int& p1) {
+    rs = re = p0 = p1 = 0;
+    if (tile >= tr.end) return;
+    const int64_t r0 = tile * kSpmvRows, r = r0 + tid;
     if (r < n) {
       rs = rowptr[r];
       re = rowptr[r + 1];
     }
     const int64_t rend = (r0 + kSpmvRows < n) ? r0 + kSpmvRows : n;
-    const int p0 = rowptr[r0];
-    const int p1 = rowptr[rend];
+    p0 = rowptr[r0];
+    p1 = rowptr[rend];
+  };
+  int rs, re, p0, p1;
+  tile_rows(tr.first, rs, re, p0, p1);
+  for (int64_t tile = tr.first; tile < tr.end; tile += tr.step) {
+    const int64_t r = tile * kSpmvRows + tid;
+    int nrs, nre, np0, np1;
+    tile_rows(tile + tr.step, nrs, nre, np0, np1);
     const int pa = p0 & ~3;  // aligned start: int4 / double2 loads
     double sum = 0.0;
     for (int cb = pa; cb < p1; cb += kSpmvChunk) {
       const int cend = (cb + kSpmvChunk < p1) ? cb + kSpmvChunk : p1;
-      // phase 1: entries outside [p0, p1) are valid neighbours' entries or the zero
-      // padding behind nnz; their products are written but never read.
-      for (int q = cb + 4 * tid; q < cend; q += 4 * kBlock) {
-        const int4 c4 = *reinterpret_cast<const int4*>(col + q);
-        const double2 v01 = ld2(val + q);
-        const double2 v23 = ld2(val + q + 2);
-        const double x0 = x_ext[c4.x] * scale;
-        const double x1 = x_ext[c4.y] * scale;
-        const double x2 = x_ext[c4.z] * scale;
-        const double x3 = x_ext[c4.w] * scale;
-        const int li = skew(q - cb);  // 4 consecutive entries never straddle a multiple of 32
-        prod[li + 0] = v01.x * x0;
-        prod[li + 1] = v01.y * x1;
-        prod[li + 2] = v23.x * x2;
-        prod[li + 3] = v23.y * x3;
+      // phase 1: a chunk is two rounds of 4 entries per lane; all six 16-byte loads are issued before
+      // the first use, then the eight gathers.  Entries outside [p0, p1) are valid neighbours' entries
+      // or the zero padding behind nnz; their products are written but never read.
+      const int q0 = cb + 4 * tid, q1 = q0 + 4 * kBlock;
+      const bool in0 = q0 < cend, in1 = q1 < cend;
+      int4 ca = make_int4(0, 0, 0, 0), cbv = make_int4(0, 0, 0, 0);
+      double2 a01 = make_double2(0.0, 0.0), a23 = a01, b01 = a01, b23 = a01;
+      if (in0) {
+        ca = *reinterpret_cast<const int4*>(col + q0);
+        a01 = ld2(val + q0);
+        a23 = ld2(val + q0 + 2);
+      }
+      if (in1) {
+        cbv = *reinterpret_cast<const int4*>(col + q1);
+        b01 = ld2(val + q1);
+        b23 = ld2(val + q1 + 2);
+      }
+      if (in0) {
+        const double x0 = x_ext[ca.x] * scale, x1 = x_ext[ca.y] * scale;
+        const double x2 = x_ext[ca.z] * scale, x3 = x_ext[ca.w] * scale;
+        const int li = skew(q0 - cb);  // 4 consecutive entries never straddle a multiple of 32
+        prod[li + 0] = a01.x * x0;
+        prod[li + 1] = a01.y * x1;
+        prod[li + 2] = a23.x * x2;
+        prod[li + 3] = a23.y * x3;
+      }
+      if (in1) {
+        const double x0 = x_ext[cbv.x] * scale, x1 = x_ext[cbv.y] * scale;
+        const double x2 = x_ext[cbv.z] * scale, x3 = x_ext[cbv.w] * scale;
+        const int li = skew(q1 - cb);
+        prod[li + 0] = b01.x * x0;
+        prod[li + 1] = b01.y * x1;
+        prod[li + 2] = b23.x * x2;
+        prod[li + 3] = b23.y * x3;
       }
       __syncthreads();
       // phase 2: stored order, multiply-then-add
@@ -430,6 +458,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int32_t* __restrict__ row
       if (u_out) u_out[r] = xr;
       dot = fma(xr, yr, dot);
     }
+    rs = nrs, re = nre, p0 = np0, p1 = np1;
   }
   if (partials) {
     dot = block_sum(dot, lds4);
