@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libeigenex_hip.so")
 
 ORTHO_BATCHED = 0
 ORTHO_SEQUENTIAL = 1
+ORTHO_BATCHED_TWICE = 2
 VEC_V = -1
 VEC_W = -2
 VEC_START = -3
@@ -92,6 +93,7 @@ SIGNATURES = {
     "eigenex_scale": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double]),
     "eigenex_lanczos_enqueue": (C.c_int, [_vp, C.c_int]),
     "eigenex_arnoldi_enqueue": (C.c_int, [_vp, C.c_int]),
+    "eigenex_lanczos_restart": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double]),
     "eigenex_lanczos_state": (C.c_int, [_vp, C.POINTER(State), _dp, _dp]),
     "eigenex_arnoldi_state": (C.c_int, [_vp, C.POINTER(State), _dp, C.c_int]),
     "eigenex_ritz_vectors": (C.c_int, [_vp, C.c_int, C.c_int, _dp, C.c_int, _dp, C.c_int64]),
@@ -337,6 +339,11 @@ class Basis:
     # -- fused steps
     def lanczos_enqueue(self, ncalls: int):
         _chk(lib().eigenex_lanczos_enqueue(self.h, ncalls))
+
+    def lanczos_restart(self, S, coupling_last: float):
+        """thick restart: keep the Ritz vectors V_m S (S: m x nkeep, real)"""
+        S = np.asfortranarray(S, np.float64)
+        _chk(lib().eigenex_lanczos_restart(self.h, S.shape[1], _d(S), S.shape[0], float(coupling_last)))
 
     def arnoldi_enqueue(self, ncalls: int):
         _chk(lib().eigenex_arnoldi_enqueue(self.h, ncalls))

@@ -689,6 +689,24 @@ __global__ void k_arnoldi_end(Ctrl* ctrl, const double* h, double* H, int ldh, i
   }
 }
 
+// dst[i] += src[i] (coefficients of a second Gram-Schmidt pass folded into the first)
+__global__ void k_add_small(double* dst, const double* src, int n, const Ctrl* ctrl) {
+  if (ctrl->stopped) return;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] += src[i];
+}
+
+// thick restart: the kept Ritz vectors sit in columns 0..nkeep-1, the old residual vector u_m in column
+// nkeep; T' = diag(theta) bordered by the couplings, so alpha[nkeep] = old alpha[m], beta[nkeep-1] = s_{nkeep-1}
+__global__ void k_restart_fix(Ctrl* ctrl, double* alpha, double* beta, int m, int nkeep, double coupling_last) {
+  if (threadIdx.x != 0) return;
+  alpha[nkeep] = alpha[m];
+  if (nkeep > 0) beta[nkeep - 1] = coupling_last;
+  ctrl->stopped = 0;
+  ctrl->nvec = nkeep + 1;
+  ctrl->nalpha = nkeep + 1;
+  ctrl->nbeta = nkeep;
+}
+
 __global__ void k_accept_vector(Ctrl* ctrl) {
   if (threadIdx.x != 0 || ctrl->stopped) return;
   ctrl->nvec++;
@@ -978,6 +996,14 @@ void launch_arnoldi_begin(hipStream_t s, Ctrl* ctrl, double threshold, int64_t n
 
 void launch_arnoldi_end(hipStream_t s, Ctrl* ctrl, const double* h, double* H, int ldh, int es) {
   hipLaunchKernelGGL(k_arnoldi_end, dim3(1), dim3(kBlock), 0, s, ctrl, h, H, ldh, es);
+}
+
+void launch_add_small(hipStream_t s, double* dst, const double* src, int n, const Ctrl* ctrl) {
+  if (n > 0) hipLaunchKernelGGL(k_add_small, dim3(1), dim3(kBlock), 0, s, dst, src, n, ctrl);
+}
+
+void launch_restart_fix(hipStream_t s, Ctrl* ctrl, double* alpha, double* beta, int m, int nkeep, double coupling_last) {
+  hipLaunchKernelGGL(k_restart_fix, dim3(1), dim3(64), 0, s, ctrl, alpha, beta, m, nkeep, coupling_last);
 }
 
 void launch_accept_vector(hipStream_t s, Ctrl* ctrl) {

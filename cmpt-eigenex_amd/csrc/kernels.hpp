@@ -95,6 +95,8 @@ void launch_arnoldi_begin(hipStream_t s, Ctrl* ctrl, double threshold, int64_t n
                           int es);
 // Arnoldi end of a call: H[0..k][k] = h[0..k], H[k+1][k] = 0, ++iterations
 void launch_arnoldi_end(hipStream_t s, Ctrl* ctrl, const double* h, double* H, int ldh, int es);
+void launch_add_small(hipStream_t s, double* dst, const double* src, int n, const Ctrl* ctrl);
+void launch_restart_fix(hipStream_t s, Ctrl* ctrl, double* alpha, double* beta, int m, int nkeep, double coupling_last);
 // vector accepted into the basis: ++nvec  (after the operator has been applied with `scale`)
 void launch_accept_vector(hipStream_t s, Ctrl* ctrl);
 

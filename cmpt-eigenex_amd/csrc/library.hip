@@ -212,6 +212,7 @@ struct eigenex_basis_s {
   int slot_alpha() const { return es * maxcols + 1; }  // (re, im) for complex
   int slot_a() const { return es * maxcols + 4; }
   int slot_b() const { return es * maxcols + 5; }
+  int base_h2() const { return es * maxcols + 8; }  // coefficients of the second Gram-Schmidt pass
 };
 
 namespace {
@@ -465,7 +466,7 @@ ColumnSet colset(BasisShard& s, int first, int stride, int count, int qfirst, in
 // ---- enqueue helpers (all local shards, then the collective) -----------------
 // h[slot .. slot+ncols) = all-reduced dots of w0(src, tt) with the column set
 int enq_dots(eigenex_basis_s* b, int src_ref, bool three_term, int k, int first, int stride, int count, int qfirst,
-             int nq, int slot, bool use_ctrl) {
+             int nq, int slot, bool use_ctrl, int base = 0) {
   eigenex_context_s* c = b->ctx;
   const int ncols = count + nq;
   if (ncols <= 0) return 0;
@@ -479,14 +480,14 @@ int enq_dots(eigenex_basis_s* b, int src_ref, bool three_term, int k, int first,
                   s.partials, s.pstride, s.g_vec, ctl, b->es == 2);
     }
     ProfScope ps(c, EIGENEX_K_SMALL, 0.0);
-    launch_reduce(c->stream, s.partials, s.pstride, s.g_vec, ncols * b->es, s.hbuf + slot * b->es, ctl);
+    launch_reduce(c->stream, s.partials, s.pstride, s.g_vec, ncols * b->es, s.hbuf + base + slot * b->es, ctl);
   }
-  return allreduce(b, slot * b->es, ncols * b->es);
+  return allreduce(b, base + slot * b->es, ncols * b->es);
 }
 
 // dst = w0(src, tt) - sum h[slot+c]*col_c ; hbuf[slot_nrm] = all-reduced ||dst||^2 (if want_norm)
 int enq_update(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_term, int k, int first, int stride, int count,
-               int qfirst, int nq, int slot, bool want_norm, bool use_ctrl) {
+               int qfirst, int nq, int slot, bool want_norm, bool use_ctrl, int base = 0) {
   eigenex_context_s* c = b->ctx;
   const int ncols = count + nq;
   for (auto& s : b->sh) {
@@ -496,7 +497,7 @@ int enq_update(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_term, in
     {
       ProfScope ps(c, EIGENEX_K_UPDATE, 8.0 * s.nd * ncols + 24.0 * s.nd + (three_term ? 32.0 * s.nd : 0.0));
       launch_update(c->stream, vec_ptr(s, b->cap, b->nq, src_ref), vec_ptr(s, b->cap, b->nq, dst_ref), tt,
-                    colset(s, first, stride, count, qfirst, nq), s.hbuf + slot * b->es, s.nd, s.partials, s.g_vec, ctl,
+                    colset(s, first, stride, count, qfirst, nq), s.hbuf + base + slot * b->es, s.nd, s.partials, s.g_vec, ctl,
                     b->es == 2);
     }
     if (want_norm) {
@@ -514,9 +515,16 @@ int enq_update(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_term, in
 // lanczos.hpp:416-425).
 int enq_orthogonalize(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_term, int k, int first, int stride,
                       int count, int nq, bool q_first) {
-  if (b->ortho_mode == EIGENEX_ORTHO_BATCHED) {
+  if (b->ortho_mode == EIGENEX_ORTHO_BATCHED || b->ortho_mode == EIGENEX_ORTHO_BATCHED_TWICE) {
+    const bool twice = b->ortho_mode == EIGENEX_ORTHO_BATCHED_TWICE && count + nq > 0;
     CHK(enq_dots(b, src_ref, three_term, k, first, stride, count, 0, nq, 0, true));
-    return enq_update(b, src_ref, dst_ref, three_term, k, first, stride, count, 0, nq, 0, true, true);
+    CHK(enq_update(b, src_ref, dst_ref, three_term, k, first, stride, count, 0, nq, 0, !twice, true));
+    if (!twice) return 0;
+    // second pass on the result itself ("twice is enough"): h += V^H w, w -= V (V^H w)
+    CHK(enq_dots(b, dst_ref, false, 0, first, stride, count, 0, nq, 0, true, b->base_h2()));
+    CHK(enq_update(b, dst_ref, dst_ref, false, 0, first, stride, count, 0, nq, 0, true, true, b->base_h2()));
+    for (auto& s : b->sh) launch_add_small(b->ctx->stream, s.hbuf, s.hbuf + b->base_h2(), (count + nq) * b->es, s.ctrl);
+    return 0;
   }
   // sequential modified Gram-Schmidt
   const int total = count + nq;
@@ -1110,8 +1118,8 @@ int eigenex_basis_create_ex(eigenex_context_t c, eigenex_csr_t csr, int64_t n_gl
                            grid_for_tiles((s.nloc + kSpmvRows - 1) / kSpmvRows, kMaxBlocksPerCu));
       const int rows = 2 * std::max(b->maxcols, 8) + 4;
       HIPCHK(hipMalloc(&s.partials, sizeof(double) * (size_t)s.pstride * rows));
-      HIPCHK(hipMalloc(&s.hbuf, sizeof(double) * (2 * b->maxcols + 40)));
-      HIPCHK(hipMemsetAsync(s.hbuf, 0, sizeof(double) * (2 * b->maxcols + 40), c->stream));
+      HIPCHK(hipMalloc(&s.hbuf, sizeof(double) * (4 * b->maxcols + 48)));
+      HIPCHK(hipMemsetAsync(s.hbuf, 0, sizeof(double) * (4 * b->maxcols + 48), c->stream));
       HIPCHK(hipMalloc(&s.alpha, sizeof(double) * (capacity + 2)));
       HIPCHK(hipMalloc(&s.beta, sizeof(double) * (capacity + 2)));
       HIPCHK(hipMemsetAsync(s.alpha, 0, sizeof(double) * (capacity + 2), c->stream));
@@ -1174,8 +1182,8 @@ int eigenex_basis_reserve(eigenex_basis_t b, int capacity) {
     HIPCHK(hipMemsetAsync(V + (size_t)s.ldd * oldcap, 0, vbytes * (capacity - oldcap), c->stream));
     const int rows = 2 * std::max(newmax, 8) + 4;
     HIPCHK(hipMalloc(&partials, sizeof(double) * (size_t)s.pstride * rows));
-    HIPCHK(hipMalloc(&hbuf, sizeof(double) * (2 * newmax + 40)));
-    HIPCHK(hipMemsetAsync(hbuf, 0, sizeof(double) * (2 * newmax + 40), c->stream));
+    HIPCHK(hipMalloc(&hbuf, sizeof(double) * (4 * newmax + 48)));
+    HIPCHK(hipMemsetAsync(hbuf, 0, sizeof(double) * (4 * newmax + 48), c->stream));
     HIPCHK(hipMalloc(&alpha, sizeof(double) * (capacity + 2)));
     HIPCHK(hipMalloc(&beta, sizeof(double) * (capacity + 2)));
     HIPCHK(hipMemsetAsync(alpha, 0, sizeof(double) * (capacity + 2), c->stream));
@@ -1211,7 +1219,7 @@ int eigenex_basis_configure(eigenex_basis_t b, double eigenvalue_shift, double t
 int eigenex_basis_configure_z(eigenex_basis_t b, double shift_re, double shift_im, double threshold, int64_t interval,
                               int ortho_mode) {
   if (!b) return fail(EIGENEX_ERR_ARG, "basis is NULL");
-  if (ortho_mode != EIGENEX_ORTHO_BATCHED && ortho_mode != EIGENEX_ORTHO_SEQUENTIAL) return fail(EIGENEX_ERR_ARG, "bad ortho_mode");
+  if (ortho_mode < EIGENEX_ORTHO_BATCHED || ortho_mode > EIGENEX_ORTHO_BATCHED_TWICE) return fail(EIGENEX_ERR_ARG, "bad ortho_mode");
   if (shift_im != 0.0 && b->es != 2) return fail(EIGENEX_ERR_ARG, "a complex shift needs a complex basis");
   b->shift = shift_re;
   b->shift_im = shift_im;
@@ -1373,6 +1381,47 @@ int eigenex_lanczos_enqueue(eigenex_basis_t b, int ncalls) {
   if (!b || ncalls < 0) return fail(EIGENEX_ERR_ARG, "bad argument");
   HIPCHK(hipSetDevice(b->ctx->device));
   for (int i = 0; i < ncalls; ++i) CHK(lanczos_call(b));
+  return 0;
+}
+
+// Thick restart (Wu & Simon): with m+1 Lanczos vectors on the device (u_0..u_m, v = A u_m, alpha[m] known),
+// replace the basis by nkeep Ritz vectors Y = V_m S followed by u_m and continue from there.  The products
+// are formed in the free columns m+1.. of the slab (capacity >= m+1+nkeep) and copied down.
+int eigenex_lanczos_restart(eigenex_basis_t b, int nkeep, const double* S, int lds, double coupling_last) {
+  if (!b || nkeep < 1 || !S) return fail(EIGENEX_ERR_ARG, "eigenex_lanczos_restart: bad argument");
+  eigenex_context_s* c = b->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  Ctrl ct;
+  CHK(sync_ctrl(b, &ct));
+  const int m = ct.nvec - 1;  // Ritz vectors are combinations of u_0..u_{m-1}; u_m is the residual direction
+  if (ct.stopped || m < 1 || ct.nalpha != m + 1) return fail(EIGENEX_ERR_STATE, "eigenex_lanczos_restart: no complete Lanczos state to restart from");
+  if (nkeep > m || lds < m) return fail(EIGENEX_ERR_ARG, "eigenex_lanczos_restart: nkeep/lds out of range");
+  if (b->cap < m + 1 + nkeep) return fail(EIGENEX_ERR_STATE, "eigenex_lanczos_restart: capacity must be >= nvec + nkeep (scratch columns)");
+  const int E = 8;
+  double* d_S = nullptr;
+  HIPCHK(hipMalloc(&d_S, sizeof(double) * (size_t)m * E));
+  int rc = [&]() -> int {
+    for (int e0 = 0; e0 < nkeep; e0 += E) {
+      const int ne = std::min(E, nkeep - e0);
+      for (int e = 0; e < ne; ++e)
+        HIPCHK(hipMemcpyAsync(d_S + (size_t)e * m, S + (size_t)(e0 + e) * lds, sizeof(double) * m, hipMemcpyHostToDevice, c->stream));
+      for (auto& s : b->sh) {
+        ProfScope ps(c, EIGENEX_K_RITZ, 8.0 * s.nd * m + 8.0 * s.nd * ne);
+        launch_ritz(c->stream, s.V, s.ldd, m, d_S, m, ne, s.V + (size_t)(m + 1 + e0) * s.ldd, s.ldd, s.nd, s.partials, s.pstride, s.g_vec);
+      }
+      HIPCHK(hipStreamSynchronize(c->stream));  // d_S is reused by the next chunk
+    }
+    for (auto& s : b->sh) {
+      const size_t vb = sizeof(double) * (size_t)s.ldd;
+      HIPCHK(hipMemcpyAsync(s.V, s.V + (size_t)(m + 1) * s.ldd, vb * nkeep, hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(hipMemcpyAsync(s.V + (size_t)nkeep * s.ldd, s.V + (size_t)m * s.ldd, vb, hipMemcpyDeviceToDevice, c->stream));
+      launch_restart_fix(c->stream, s.ctrl, s.alpha, s.beta, m, nkeep, coupling_last);
+    }
+    return 0;
+  }();
+  (void)hipFree(d_S);
+  if (rc) return rc;
+  b->h_nvec = nkeep + 1;
   return 0;
 }
 

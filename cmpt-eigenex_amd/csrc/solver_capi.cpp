@@ -18,6 +18,7 @@
 
 #include "cmpt/eigen_ex/arnoldi.hpp"
 #include "cmpt/eigen_ex/lanczos.hpp"
+#include "cmpt/eigen_ex/thick_restart_lanczos.hpp"
 
 using namespace cmpt::EigenEx;
 
@@ -221,6 +222,48 @@ int ar_get(void* p, double* hess, double* eigenvalues, double* eigenvectors, dou
   });
 }
 
+// ---- thick-restart Lanczos -----------------------------------------------------------------
+template <class S>
+int tr_set(void* p, const char* key, double v) {
+  return guard([&] {
+    auto& es = static_cast<Box<ThickRestartLanczosEigenSolver<S>>*>(p)->es;
+    const std::string k(key);
+    if (k == "numberOfEigenvalues") es.setNumberOfEigenvalues((Index)v);
+    else if (k == "maxBasisSize") es.setMaxBasisSize((Index)v);
+    else if (k == "keepSize") es.setKeepSize((Index)v);
+    else if (k == "tolerance") es.setTolerance(v);
+    else if (k == "maxRestarts") es.setMaxRestarts((Index)v);
+    else if (k == "computeEigenvectorsOn") es.setComputeEigenvectorsOn(v != 0.0);
+    else if (k == "eigenvalueShift") es.setEigenvalueShift(v);
+    else if (k == "threshold") es.setThreshold(v);
+    else throw LanczosException("unknown setting: " + k);
+  });
+}
+// sizes: [neigenvalues, eigvec_rows, eigvec_cols, restarts, operatorApplications, nlog, info]
+template <class S>
+int tr_sizes(void* p, int64_t* out) {
+  return guard([&] {
+    auto& es = static_cast<Box<ThickRestartLanczosEigenSolver<S>>*>(p)->es;
+    out[0] = es.eigenvalues().size();
+    out[1] = es.eigenvectors().rows();
+    out[2] = es.eigenvectors().cols();
+    out[3] = es.restarts();
+    out[4] = es.operatorApplications();
+    out[5] = (int64_t)es.log().size();
+    out[6] = (int64_t)es.info();
+  });
+}
+template <class S>
+int tr_get(void* p, double* eigenvalues, double* residuals, double* eigenvectors) {
+  return guard([&] {
+    auto& es = static_cast<Box<ThickRestartLanczosEigenSolver<S>>*>(p)->es;
+    if (eigenvalues) std::copy(es.eigenvalues().begin(), es.eigenvalues().end(), eigenvalues);
+    if (residuals) std::copy(es.residuals().begin(), es.residuals().end(), residuals);
+    if (eigenvectors && es.eigenvectors().size())
+      std::memcpy(eigenvectors, es.eigenvectors().data(), sizeof(S) * (size_t)es.eigenvectors().size());
+  });
+}
+
 }  // namespace
 
 extern "C" {
@@ -258,6 +301,15 @@ int eigenex_solver_tridiagonal_eigen(int n, const double* diag, const double* su
     if (!small_eigen::tridiagonal(diag, sub, n, vals, vectors ? &vecs : nullptr)) throw LanczosException("QL iteration did not converge");
     std::copy(vals.begin(), vals.end(), values);
     if (vectors) std::copy(vecs.begin(), vecs.end(), vectors);
+  });
+}
+// dense symmetric (column-major n x n); vectors column-major
+int eigenex_solver_symmetric_eigen(int n, const double* A, double* values, double* vectors) {
+  return guard([&] {
+    std::vector<double> a(A, A + (size_t)n * n), vals, vecs;
+    if (!small_eigen::symmetric(a, n, vals, vecs)) throw LanczosException("QL iteration did not converge");
+    std::copy(vals.begin(), vals.end(), values);
+    std::copy(vecs.begin(), vecs.end(), vectors);
   });
 }
 // H: column-major n x n complex (interleaved re,im); values/vectors interleaved
@@ -314,6 +366,33 @@ int eigenex_solver_hessenberg_eigen(int n, const double* H_interleaved, double* 
   int PFX##sizes(void* p, int64_t* out) { return ar_sizes<S>(p, out); }                                                 \
   int PFX##get(void* p, double* H, double* ev, double* X, double* res) { return ar_get<S>(p, H, ev, X, res); }
 
+#define EIGENEX_TRLANCZOS_FAMILY(PFX, S)                                                                                \
+  void* PFX##create(void) {                                                                                             \
+    try {                                                                                                               \
+      return new Box<ThickRestartLanczosEigenSolver<S>>();                                                              \
+    } catch (const std::exception& e) {                                                                                 \
+      g_serr = e.what();                                                                                                \
+      return nullptr;                                                                                                   \
+    }                                                                                                                   \
+  }                                                                                                                     \
+  void PFX##destroy(void* p) { delete static_cast<Box<ThickRestartLanczosEigenSolver<S>>*>(p); }                        \
+  int PFX##set_device_operator(void* p, eigenex_context_t ctx, eigenex_csr_t csr) {                                     \
+    return sv_set_device_operator<ThickRestartLanczosEigenSolver<S>>(p, ctx, csr);                                      \
+  }                                                                                                                     \
+  int PFX##set_host_operator(void* p, eigenex_context_t ctx, eigenex_matvec_fn fn, void* user, int64_t height) {        \
+    return sv_set_host_operator<ThickRestartLanczosEigenSolver<S>>(p, ctx, fn, user, height);                           \
+  }                                                                                                                     \
+  int PFX##set_initial_vector(void* p, const double* v, int64_t n) {                                                    \
+    return guard([&] { static_cast<Box<ThickRestartLanczosEigenSolver<S>>*>(p)->es.setInitialVector(make_vector<S>(v, n)); }); \
+  }                                                                                                                     \
+  int PFX##set(void* p, const char* key, double v, double) { return tr_set<S>(p, key, v); }                             \
+  int PFX##compute(void* p) { return guard([&] { static_cast<Box<ThickRestartLanczosEigenSolver<S>>*>(p)->es.compute(); }); } \
+  int PFX##sizes(void* p, int64_t* out) { return tr_sizes<S>(p, out); }                                                 \
+  int PFX##get(void* p, double* ev, double* res, double* X) { return tr_get<S>(p, ev, res, X); }                        \
+  const char* PFX##log_line(void* p, int64_t i) { return sv_log_line<ThickRestartLanczosEigenSolver<S>>(p, i); }
+
+EIGENEX_TRLANCZOS_FAMILY(eigenex_trlanczos_solver_, double)
+EIGENEX_TRLANCZOS_FAMILY(eigenex_ztrlanczos_solver_, std::complex<double>)
 EIGENEX_LANCZOS_FAMILY(eigenex_lanczos_solver_, double)
 EIGENEX_LANCZOS_FAMILY(eigenex_zlanczos_solver_, std::complex<double>)
 EIGENEX_ARNOLDI_FAMILY(eigenex_arnoldi_solver_, double)

@@ -106,6 +106,65 @@ inline bool tridiagonal(const double* diag, const double* sub, int n, std::vecto
   return ok;
 }
 
+// Dense real symmetric eigenproblem (column-major n x n in A, destroyed): Householder reduction to
+// tridiagonal form with accumulated reflectors, then the QL iteration above; eigenvectors = Q * Z.
+// Used by the thick-restart solver, whose projected matrix is diag(theta) bordered by one row of
+// couplings plus a tridiagonal tail.  values ascending; vectors column-major n x n.
+inline bool symmetric(std::vector<double>& A, int n, std::vector<double>& values, std::vector<double>& vectors) {
+  auto a = [&](int r, int c) -> double& { return A[static_cast<std::size_t>(r) + static_cast<std::size_t>(c) * n]; };
+  std::vector<double> Q(static_cast<std::size_t>(n) * n, 0.0);
+  auto q = [&](int r, int c) -> double& { return Q[static_cast<std::size_t>(r) + static_cast<std::size_t>(c) * n]; };
+  for (int i = 0; i < n; ++i) q(i, i) = 1.0;
+  std::vector<double> v(static_cast<std::size_t>(n)), p(static_cast<std::size_t>(n));
+  for (int k = 0; k + 2 < n; ++k) {
+    double nrm2 = 0.0;
+    for (int i = k + 1; i < n; ++i) nrm2 += a(i, k) * a(i, k);
+    double tail2 = nrm2 - a(k + 1, k) * a(k + 1, k);
+    if (tail2 <= 0.0) continue;  // column already tridiagonal
+    const double nrm = std::sqrt(nrm2);
+    const double alpha = a(k + 1, k) > 0.0 ? -nrm : nrm;
+    for (int i = k + 1; i < n; ++i) v[static_cast<std::size_t>(i)] = a(i, k);
+    v[static_cast<std::size_t>(k + 1)] -= alpha;
+    double vn = 0.0;
+    for (int i = k + 1; i < n; ++i) vn += v[static_cast<std::size_t>(i)] * v[static_cast<std::size_t>(i)];
+    vn = std::sqrt(vn);
+    for (int i = k + 1; i < n; ++i) v[static_cast<std::size_t>(i)] /= vn;
+    // p = A22 v ; K = v.p ; A22 -= 2 (v w^T + w v^T) with w = p - K v
+    double K = 0.0;
+    for (int i = k + 1; i < n; ++i) {
+      double s = 0.0;
+      for (int j = k + 1; j < n; ++j) s += a(i, j) * v[static_cast<std::size_t>(j)];
+      p[static_cast<std::size_t>(i)] = s;
+      K += s * v[static_cast<std::size_t>(i)];
+    }
+    for (int i = k + 1; i < n; ++i) p[static_cast<std::size_t>(i)] -= K * v[static_cast<std::size_t>(i)];
+    for (int j = k + 1; j < n; ++j)
+      for (int i = k + 1; i < n; ++i)
+        a(i, j) -= 2.0 * (v[static_cast<std::size_t>(i)] * p[static_cast<std::size_t>(j)] + p[static_cast<std::size_t>(i)] * v[static_cast<std::size_t>(j)]);
+    a(k + 1, k) = a(k, k + 1) = alpha;
+    for (int i = k + 2; i < n; ++i) a(i, k) = a(k, i) = 0.0;
+    // Q <- Q (I - 2 v v^T)
+    for (int r = 0; r < n; ++r) {
+      double s = 0.0;
+      for (int j = k + 1; j < n; ++j) s += q(r, j) * v[static_cast<std::size_t>(j)];
+      s *= 2.0;
+      for (int j = k + 1; j < n; ++j) q(r, j) -= s * v[static_cast<std::size_t>(j)];
+    }
+  }
+  std::vector<double> d(static_cast<std::size_t>(n)), e(static_cast<std::size_t>(n > 0 ? n : 1), 0.0), Z;
+  for (int i = 0; i < n; ++i) d[static_cast<std::size_t>(i)] = a(i, i);
+  for (int i = 0; i + 1 < n; ++i) e[static_cast<std::size_t>(i)] = a(i + 1, i);
+  const bool ok = tridiagonal(d.data(), e.data(), n, values, &Z);
+  vectors.assign(static_cast<std::size_t>(n) * n, 0.0);
+  for (int c = 0; c < n; ++c)
+    for (int j = 0; j < n; ++j) {
+      const double z = Z[static_cast<std::size_t>(j) + static_cast<std::size_t>(c) * n];
+      if (z == 0.0) continue;
+      for (int r = 0; r < n; ++r) vectors[static_cast<std::size_t>(r) + static_cast<std::size_t>(c) * n] += q(r, j) * z;
+    }
+  return ok;
+}
+
 using cplx = std::complex<double>;
 
 // Eigen-decomposition of a complex upper-Hessenberg matrix H (column-major n x n,

@@ -38,6 +38,21 @@ def lib():
         L.eigenex_solver_random_vector_z.argtypes = [C.c_uint32, C.c_int64, _dp]
         L.eigenex_solver_tridiagonal_eigen.argtypes = [C.c_int, _dp, _dp, _dp, _dp]
         L.eigenex_solver_hessenberg_eigen.argtypes = [C.c_int, _dp, _dp, _dp]
+        L.eigenex_solver_symmetric_eigen.argtypes = [C.c_int, _dp, _dp, _dp]
+        for kind in ("trlanczos", "ztrlanczos"):
+            p = f"eigenex_{kind}_solver_"
+            getattr(L, p + "create").restype = _vp
+            getattr(L, p + "destroy").argtypes = [_vp]
+            getattr(L, p + "destroy").restype = None
+            getattr(L, p + "set_device_operator").argtypes = [_vp, _vp, _vp]
+            getattr(L, p + "set_host_operator").argtypes = [_vp, _vp, capi.MATVEC_FN, _vp, C.c_int64]
+            getattr(L, p + "set").argtypes = [_vp, C.c_char_p, C.c_double, C.c_double]
+            getattr(L, p + "set_initial_vector").argtypes = [_vp, _dp, C.c_int64]
+            getattr(L, p + "compute").argtypes = [_vp]
+            getattr(L, p + "sizes").argtypes = [_vp, _lp]
+            getattr(L, p + "get").argtypes = [_vp, _dp, _dp, _dp]
+            getattr(L, p + "log_line").argtypes = [_vp, C.c_int64]
+            getattr(L, p + "log_line").restype = C.c_char_p
         for kind in FAMILIES:
             p = f"eigenex_{kind}_solver_"
             getattr(L, p + "create").restype = _vp
@@ -108,6 +123,15 @@ def hessenberg_eigen(H, vectors=True):
     vals = np.empty(n, np.complex128)
     vecs = np.empty((n, n), np.complex128, order="F") if vectors else None
     _chk(lib().eigenex_solver_hessenberg_eigen(n, _d(H), _d(vals), _d(vecs) if vectors else None))
+    return vals, vecs
+
+
+def symmetric_eigen(A):
+    A = np.asfortranarray(A, np.float64)
+    n = A.shape[0]
+    vals = np.empty(n)
+    vecs = np.empty((n, n), order="F")
+    _chk(lib().eigenex_solver_symmetric_eigen(n, _d(A), _d(vals), _d(vecs)))
     return vals, vecs
 
 
@@ -237,4 +261,24 @@ class ArnoldiEigenSolver(_SolverBase):
         res = C.c_double()
         _chk(self._f("get")(self.h, _d(H) if H.size else None, _d(ev), _d(X) if X.size else None, C.byref(res)))
         s.update(hessenberg=H, eigenvalues=ev, eigenvectors=X, residue=res.value, info_name=INFO[s["info"]])
+        return s
+
+
+class ThickRestartLanczosEigenSolver(_SolverBase):
+    """ThickRestartLanczosEigenSolver<S> (thick_restart_lanczos.hpp): lowest eigenpairs with bounded memory."""
+
+    _base = "trlanczos"
+    _names = ("neig", "vec_rows", "vec_cols", "restarts", "operatorApplications", "nlog", "info")
+
+    def _sizes(self):
+        out = np.zeros(len(self._names), np.int64)
+        _chk(self._f("sizes")(self.h, out.ctypes.data_as(_lp)))
+        return dict(zip(self._names, (int(x) for x in out)))
+
+    def results(self):
+        s = self._sizes()
+        ev, res = np.zeros(s["neig"]), np.zeros(s["neig"])
+        X = np.zeros((s["vec_rows"], s["vec_cols"]), self.dtype, order="F")
+        _chk(self._f("get")(self.h, _d(ev), _d(res), _d(X) if X.size else None))
+        s.update(eigenvalues=ev, residuals=res, eigenvectors=X, info_name=INFO[s["info"]])
         return s

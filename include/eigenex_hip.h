@@ -60,7 +60,10 @@ enum {
   EIGENEX_ORTHO_BATCHED = 0,
   /* strictly sequential modified Gram-Schmidt, the reference's operation order
    * (lanczos.hpp:416-418, arnoldi.hpp:380-383): one dot + one axpy per vector */
-  EIGENEX_ORTHO_SEQUENTIAL = 1
+  EIGENEX_ORTHO_SEQUENTIAL = 1,
+  /* batched Gram-Schmidt applied twice per step ("twice is enough"): for steps whose coefficients are
+   * not small, e.g. the first step after a thick restart; doubles the traffic over the basis */
+  EIGENEX_ORTHO_BATCHED_TWICE = 2
 };
 
 /* vector references inside a basis (arguments named *_ref) */
@@ -193,6 +196,13 @@ int eigenex_scale(eigenex_basis_t b, int dst_ref, int src_ref, double s);
  * the reference would have stopped. */
 int eigenex_lanczos_enqueue(eigenex_basis_t b, int ncalls);
 int eigenex_arnoldi_enqueue(eigenex_basis_t b, int ncalls);
+/* Thick restart of a Lanczos run (not in the reference, which has no restart: SURVEY F6; built on the same
+ * device state).  Precondition: m+1 vectors u_0..u_m on the device.  S (column-major m x nkeep, leading
+ * dimension lds, real) holds the kept eigenvectors of T_m.  Afterwards columns 0..nkeep-1 are the Ritz vectors
+ * V_m S, column nkeep is u_m, v_ and alpha[nkeep] are those of u_m, beta[nkeep-1] = coupling_last
+ * (= beta_{m-1} * S[m-1, nkeep-1]); the next eigenex_lanczos_enqueue continues from there (full
+ * re-orthogonalisation supplies the remaining couplings).  Needs capacity >= (m+1) + nkeep. Synchronises. */
+int eigenex_lanczos_restart(eigenex_basis_t b, int nkeep, const double* S, int lds, double coupling_last);
 
 typedef struct {
   int32_t nvec;        /* lanczosvectors_.size() / arnoldivectors_.size() */
