@@ -23,7 +23,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name: str) -> str:
-    name = name.split("(")[0] if not name.startswith("eigenex::(") else name[len("eigenex::(anonymous namespace)::"):].split("(")[0]
+    """'void eigenex::(anonymous namespace)::k_dots<false, true>(double const*, ...)' -> 'k_dots'"""
+    name = name.strip()
+    if name.startswith("void "):
+        name = name[5:]
+    name = name.replace("eigenex::(anonymous namespace)::", "").replace("eigenex::", "")
+    for sep in ("<", "("):
+        if sep in name:
+            name = name.split(sep)[0]
     return name.strip()
 
 
@@ -42,7 +49,17 @@ def main():
     os.makedirs(out_dir, exist_ok=True)
     stats_file = glob.glob(os.path.join(stats_dir, "**", "*_kernel_stats.csv"), recursive=True)[0]
     shutil.copy(stats_file, os.path.join(out_dir, f"{rnd}_kernel_stats.csv"))
-    stats = {short(r["Name"]): r for r in csv.DictReader(open(stats_file))}
+    stats = {}
+    for r in csv.DictReader(open(stats_file)):
+        k = short(r["Name"])
+        if k in stats:  # template instantiations of one kernel
+            a = stats[k]
+            calls = int(a["Calls"]) + int(r["Calls"])
+            tot = float(a["TotalDurationNs"]) + float(r["TotalDurationNs"])
+            a.update(Calls=str(calls), TotalDurationNs=str(tot), AverageNs=str(tot / calls),
+                     Percentage=str(float(a["Percentage"]) + float(r["Percentage"])))
+        else:
+            stats[k] = dict(r)
     fetch = load_counter(fetch_dir, "FETCH_SIZE")
     write = load_counter(write_dir, "WRITE_SIZE")
     traffic = {}
