@@ -19,6 +19,7 @@
 #include "cmpt/eigen_ex/arnoldi.hpp"
 #include "cmpt/eigen_ex/lanczos.hpp"
 #include "cmpt/eigen_ex/thick_restart_lanczos.hpp"
+#include "cmpt/eigen_ex/triplets_operator.hpp"
 
 using namespace cmpt::EigenEx;
 
@@ -301,6 +302,37 @@ int eigenex_solver_tridiagonal_eigen(int n, const double* diag, const double* su
     if (!small_eigen::tridiagonal(diag, sub, n, vals, vectors ? &vecs : nullptr)) throw LanczosException("QL iteration did not converge");
     std::copy(vals.begin(), vals.end(), values);
     if (vectors) std::copy(vecs.begin(), vecs.end(), vectors);
+  });
+}
+// COO -> CSR (TripletsMatrix::shrink semantics); out arrays sized count / n+1; returns nnz in *nnz
+int eigenex_solver_triplets_to_csr(int64_t n, int64_t count, const int64_t* rows, const int64_t* cols, const double* vals,
+                                   int is_complex, int32_t* rowptr, int32_t* col, double* val, int64_t* nnz) {
+  return guard([&] {
+    std::vector<Index> r(rows, rows + count), c(cols, cols + count);
+    if (is_complex) {
+      auto m = triplets_to_csr<std::complex<double>>((Index)n, (Index)count, r.data(), c.data(), reinterpret_cast<const std::complex<double>*>(vals));
+      std::copy(m.rowptr.begin(), m.rowptr.end(), rowptr);
+      std::copy(m.col.begin(), m.col.end(), col);
+      std::memcpy(val, m.val.data(), sizeof(double) * 2 * m.val.size());
+      *nnz = (int64_t)m.val.size();
+    } else {
+      auto m = triplets_to_csr<double>((Index)n, (Index)count, r.data(), c.data(), vals);
+      std::copy(m.rowptr.begin(), m.rowptr.end(), rowptr);
+      std::copy(m.col.begin(), m.col.end(), col);
+      std::copy(m.val.begin(), m.val.end(), val);
+      *nnz = (int64_t)m.val.size();
+    }
+  });
+}
+int eigenex_solver_gershgorin_range(int64_t n, int64_t count, const int64_t* rows, const int64_t* cols, const double* vals,
+                                    int is_complex, double* lo_hi) {
+  return guard([&] {
+    std::vector<Index> r(rows, rows + count), c(cols, cols + count);
+    const auto b = is_complex ? estimateEigenvalueRange<std::complex<double>>((Index)n, (Index)count, r.data(), c.data(),
+                                                                             reinterpret_cast<const std::complex<double>*>(vals))
+                              : estimateEigenvalueRange<double>((Index)n, (Index)count, r.data(), c.data(), vals);
+    lo_hi[0] = b[0];
+    lo_hi[1] = b[1];
   });
 }
 // dense symmetric (column-major n x n); vectors column-major

@@ -39,6 +39,9 @@ def lib():
         L.eigenex_solver_tridiagonal_eigen.argtypes = [C.c_int, _dp, _dp, _dp, _dp]
         L.eigenex_solver_hessenberg_eigen.argtypes = [C.c_int, _dp, _dp, _dp]
         L.eigenex_solver_symmetric_eigen.argtypes = [C.c_int, _dp, _dp, _dp]
+        _ip32 = C.POINTER(C.c_int32)
+        L.eigenex_solver_triplets_to_csr.argtypes = [C.c_int64, C.c_int64, _lp, _lp, _dp, C.c_int, _ip32, _ip32, _dp, _lp]
+        L.eigenex_solver_gershgorin_range.argtypes = [C.c_int64, C.c_int64, _lp, _lp, _dp, C.c_int, _dp]
         for kind in ("trlanczos", "ztrlanczos"):
             p = f"eigenex_{kind}_solver_"
             getattr(L, p + "create").restype = _vp
@@ -133,6 +136,33 @@ def symmetric_eigen(A):
     vecs = np.empty((n, n), order="F")
     _chk(lib().eigenex_solver_symmetric_eigen(n, _d(A), _d(vals), _d(vecs)))
     return vals, vecs
+
+
+def triplets_to_csr(n, rows, cols, vals):
+    """COO -> CSR with the semantics of the reference's TripletsMatrix::shrink (sort, add duplicates, drop zeros)."""
+    rows = np.ascontiguousarray(rows, np.int64)
+    cols = np.ascontiguousarray(cols, np.int64)
+    cplx = np.iscomplexobj(vals)
+    vals = np.ascontiguousarray(vals, np.complex128 if cplx else np.float64)
+    rowptr = np.zeros(n + 1, np.int32)
+    col = np.zeros(max(rows.size, 1), np.int32)
+    val = np.zeros(max(rows.size, 1), vals.dtype)
+    nnz = C.c_int64()
+    _chk(lib().eigenex_solver_triplets_to_csr(n, rows.size, rows.ctypes.data_as(_lp), cols.ctypes.data_as(_lp), _d(vals),
+                                              1 if cplx else 0, rowptr.ctypes.data_as(C.POINTER(C.c_int32)),
+                                              col.ctypes.data_as(C.POINTER(C.c_int32)), _d(val), C.byref(nnz)))
+    return rowptr, col[: nnz.value].copy(), val[: nnz.value].copy()
+
+
+def gershgorin_range(n, rows, cols, vals):
+    rows = np.ascontiguousarray(rows, np.int64)
+    cols = np.ascontiguousarray(cols, np.int64)
+    cplx = np.iscomplexobj(vals)
+    vals = np.ascontiguousarray(vals, np.complex128 if cplx else np.float64)
+    out = np.zeros(2)
+    _chk(lib().eigenex_solver_gershgorin_range(n, rows.size, rows.ctypes.data_as(_lp), cols.ctypes.data_as(_lp), _d(vals),
+                                               1 if cplx else 0, _d(out)))
+    return out[0], out[1]
 
 
 class _SolverBase:

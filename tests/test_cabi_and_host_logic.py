@@ -145,3 +145,43 @@ def test_default_start_vector_is_the_references(built):
     w = solver.random_vector(1, 64)
     r1 = libstdcxx_normal_vector(64, seed=1)
     np.testing.assert_allclose(w, r1 / np.linalg.norm(r1), rtol=0, atol=1e-16)
+
+
+def test_triplets_to_csr_and_gershgorin(built):
+    """COO ingestion (reference TripletsMatrix::operate / shrink, triplets_matrix.hpp:238-283, :314-329) and the
+    Gershgorin range (:486-523) against the oracle's scatter-add operator and numpy."""
+    _, solver = built
+    from oracle import krylov_oracle as ko
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(3)
+    n, nt = 57, 600
+    rows, cols = rng.integers(0, n, nt), rng.integers(0, n, nt)
+    for dtype in (np.float64, np.complex128):
+        vals = rng.standard_normal(nt) + (1j * rng.standard_normal(nt) if dtype == np.complex128 else 0)
+        vals = vals.astype(dtype)
+        # duplicates that cancel exactly must disappear (shrink erases zeros)
+        r2 = np.concatenate([rows, [5, 5]])
+        c2 = np.concatenate([cols, [7, 7]])
+        v2 = np.concatenate([vals, [2.5, -2.5]]).astype(dtype)
+        rowptr, col, val = solver.triplets_to_csr(n, r2, c2, v2)
+        A = sp.csr_matrix((val, col, rowptr), shape=(n, n))
+        ref = sp.coo_matrix((v2, (r2, c2)), shape=(n, n)).tocsr()
+        assert abs(A - ref).max() < 1e-14
+        assert np.all(val != 0) and np.all(np.diff(rowptr) >= 0)
+        for r in range(n):  # sorted, no duplicate positions
+            assert np.all(np.diff(col[rowptr[r]:rowptr[r + 1]]) > 0)
+        x = rng.standard_normal(n).astype(dtype)
+        np.testing.assert_allclose(A @ x, ko.coo_operate(r2, c2, v2, n)(x), atol=1e-12)
+        lo, hi = solver.gershgorin_range(n, r2, c2, v2)
+        D = ref.toarray()
+        rad = np.abs(D).sum(axis=1) - np.abs(np.diag(D))
+        # the reference sums |v| per TRIPLET (duplicates are not merged first): bound is >= the merged one
+        assert lo <= (np.diag(D).real - rad).min() + 1e-12 and hi >= (np.diag(D).real + rad).max() - 1e-12
+        H = (D + D.conj().T) / 2
+        lo_h, hi_h = solver.gershgorin_range(n, *sp.coo_matrix(H).nonzero(), H[H.nonzero()])
+        ev = np.linalg.eigvalsh(H)
+        assert lo_h <= ev[0] and ev[-1] <= hi_h
+    # all-negative discs: lowest() instead of the reference's numeric_limits::min() (documented deviation)
+    lo, hi = solver.gershgorin_range(2, [0, 1], [0, 1], np.array([-3.0, -5.0]))
+    assert (lo, hi) == (-5.0, -3.0)
