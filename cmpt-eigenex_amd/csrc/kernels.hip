@@ -354,6 +354,19 @@ __global__ __launch_bounds__(kBlock) void k_reduce(const double* __restrict__ pa
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int skew(int i) { return i + (i >> 5); }
 
+// once-read streams (val/col): non-temporal 16-byte loads, so that they do not displace the operator
+// input x from L2 / Infinity Cache
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int4 nt_ld_i4(const int32_t* p) {
+  const v4i_t v = __builtin_nontemporal_load(reinterpret_cast<const v4i_t*>(p));
+  return make_int4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ double2 nt_ld_d2(const double* p) {
+  const v2d_t v = __builtin_nontemporal_load(reinterpret_cast<const v2d_t*>(p));
+  return make_double2(v.x, v.y);
+}
+
 // Tile schedule of a persistent SpMV workgroup.  Plain: tiles b, b+G, ...  XCD-aware (T1 of the CDNA
 // guide): workgroups b and b+8 share an XCD (round-robin dispatch), so XCD x = b%8 walks its own
 // contiguous eighth of the tiles with its G/8 workgroups; neighbouring rows' operator-input lines are
@@ -383,7 +396,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int32_t* __restrict__ row
   const double scale = scale_ptr ? *scale_ptr : 1.0;
   const int tid = threadIdx.x;
   double dot = 0.0;
-  const TileRange tr = spmv_tiles(ntiles, xcd_aware);
+  const bool nt = (xcd_aware & 2) != 0;  // flags: bit 0 = XCD-contiguous tiles, bit 1 = non-temporal val/col loads
+  const TileRange tr = spmv_tiles(ntiles, xcd_aware & 1);
   // row pointers of a tile: fetched one tile ahead, so that their latency is not part of the chain
   // rowptr -> val/col -> x that every tile otherwise pays in sequence
   auto tile_rows = [&](int64_t tile, int& rs, int& re, int& p0, int& p1) {
@@ -415,15 +429,28 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int32_t* __restrict__ row
       const bool in0 = q0 < cend, in1 = q1 < cend;
       int4 ca = make_int4(0, 0, 0, 0), cbv = make_int4(0, 0, 0, 0);
       double2 a01 = make_double2(0.0, 0.0), a23 = a01, b01 = a01, b23 = a01;
-      if (in0) {
-        ca = *reinterpret_cast<const int4*>(col + q0);
-        a01 = ld2(val + q0);
-        a23 = ld2(val + q0 + 2);
-      }
-      if (in1) {
-        cbv = *reinterpret_cast<const int4*>(col + q1);
-        b01 = ld2(val + q1);
-        b23 = ld2(val + q1 + 2);
+      if (nt) {  // wave-uniform
+        if (in0) {
+          ca = nt_ld_i4(col + q0);
+          a01 = nt_ld_d2(val + q0);
+          a23 = nt_ld_d2(val + q0 + 2);
+        }
+        if (in1) {
+          cbv = nt_ld_i4(col + q1);
+          b01 = nt_ld_d2(val + q1);
+          b23 = nt_ld_d2(val + q1 + 2);
+        }
+      } else {
+        if (in0) {
+          ca = *reinterpret_cast<const int4*>(col + q0);
+          a01 = ld2(val + q0);
+          a23 = ld2(val + q0 + 2);
+        }
+        if (in1) {
+          cbv = *reinterpret_cast<const int4*>(col + q1);
+          b01 = ld2(val + q1);
+          b23 = ld2(val + q1 + 2);
+        }
       }
       if (in0) {
         const double x0 = x_ext[ca.x] * scale, x1 = x_ext[ca.y] * scale;
@@ -496,7 +523,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_z(const int32_t* __restrict__ r
   const int tid = threadIdx.x;
   const bool has_shift = shift_re != 0.0 || shift_im != 0.0;
   double dr = 0.0, di = 0.0;
-  const TileRange tr = spmv_tiles(ntiles, xcd_aware);
+  const TileRange tr = spmv_tiles(ntiles, xcd_aware & 1);
   for (int64_t tile = tr.first; tile < tr.end; tile += tr.step) {
     const int64_t r0 = tile * kSpmvRows;
     const int64_t r = r0 + tid;

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "cmpt/eigen_ex/arnoldi.hpp"
+#include "cmpt/eigen_ex/block_operator.hpp"
 #include "cmpt/eigen_ex/lanczos.hpp"
 #include "cmpt/eigen_ex/thick_restart_lanczos.hpp"
 #include "cmpt/eigen_ex/triplets_operator.hpp"
@@ -322,6 +323,29 @@ int eigenex_solver_triplets_to_csr(int64_t n, int64_t count, const int64_t* rows
       std::copy(m.val.begin(), m.val.end(), val);
       *nnz = (int64_t)m.val.size();
     }
+  });
+}
+// Block-sparse matrix (BlockTensor<double,2> layout: partitions + dense column-major blocks) -> CSR.
+// blocks: nblocks entries (qr, qc) with values concatenated column-major in `vals`; outputs sized by the caller
+// (nnz = sum of block sizes).
+int eigenex_solver_blocks_to_csr(int nbr, const int64_t* row_sizes, int nbc, const int64_t* col_sizes, int nblocks,
+                                 const int64_t* qr, const int64_t* qc, const double* vals, int32_t* rowptr, int32_t* col,
+                                 double* val, int64_t* nnz) {
+  return guard([&] {
+    BlockSparseMatrix<double> H(std::vector<Index>(row_sizes, row_sizes + nbr), std::vector<Index>(col_sizes, col_sizes + nbc));
+    const double* p = vals;
+    for (int b = 0; b < nblocks; ++b) {
+      if (qr[b] < 0 || qr[b] >= nbr || qc[b] < 0 || qc[b] >= nbc) throw LanczosException("block index out of range");
+      DenseMatrix<double> B((Index)row_sizes[qr[b]], (Index)col_sizes[qc[b]]);
+      std::copy(p, p + B.size(), B.data());
+      p += B.size();
+      H.addBlock((Index)qr[b], (Index)qc[b], B);
+    }
+    const auto m = H.toCsr();
+    std::copy(m.rowptr.begin(), m.rowptr.end(), rowptr);
+    std::copy(m.col.begin(), m.col.end(), col);
+    std::copy(m.val.begin(), m.val.end(), val);
+    *nnz = (int64_t)m.val.size();
   });
 }
 int eigenex_solver_gershgorin_range(int64_t n, int64_t count, const int64_t* rows, const int64_t* cols, const double* vals,

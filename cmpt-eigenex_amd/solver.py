@@ -42,6 +42,7 @@ def lib():
         _ip32 = C.POINTER(C.c_int32)
         L.eigenex_solver_triplets_to_csr.argtypes = [C.c_int64, C.c_int64, _lp, _lp, _dp, C.c_int, _ip32, _ip32, _dp, _lp]
         L.eigenex_solver_gershgorin_range.argtypes = [C.c_int64, C.c_int64, _lp, _lp, _dp, C.c_int, _dp]
+        L.eigenex_solver_blocks_to_csr.argtypes = [C.c_int, _lp, C.c_int, _lp, C.c_int, _lp, _lp, _dp, _ip32, _ip32, _dp, _lp]
         for kind in ("trlanczos", "ztrlanczos"):
             p = f"eigenex_{kind}_solver_"
             getattr(L, p + "create").restype = _vp
@@ -151,6 +152,33 @@ def triplets_to_csr(n, rows, cols, vals):
     _chk(lib().eigenex_solver_triplets_to_csr(n, rows.size, rows.ctypes.data_as(_lp), cols.ctypes.data_as(_lp), _d(vals),
                                               1 if cplx else 0, rowptr.ctypes.data_as(C.POINTER(C.c_int32)),
                                               col.ctypes.data_as(C.POINTER(C.c_int32)), _d(val), C.byref(nnz)))
+    return rowptr, col[: nnz.value].copy(), val[: nnz.value].copy()
+
+
+def blocks_to_csr(row_sizes, col_sizes, blocks):
+    """BlockSparseMatrix<double>::toCsr: blocks = {(qr, qc): 2-D array}; duplicates of a block index are added."""
+    rs = np.ascontiguousarray(row_sizes, np.int64)
+    cs = np.ascontiguousarray(col_sizes, np.int64)
+    keys = list(blocks.keys()) if isinstance(blocks, dict) else [k for k, _ in blocks]
+    mats = list(blocks.values()) if isinstance(blocks, dict) else [m for _, m in blocks]
+    qr = np.array([k[0] for k in keys], np.int64)
+    qc = np.array([k[1] for k in keys], np.int64)
+    # the C side sizes every block from the partition, so a mismatch here would be an out-of-bounds read
+    for (r, c), m in zip(keys, mats):
+        if not (0 <= r < rs.size and 0 <= c < cs.size):
+            raise ValueError(f"block index ({r}, {c}) out of range")
+        if np.shape(m) != (rs[r], cs[c]):
+            raise ValueError(f"block ({r}, {c}) has shape {np.shape(m)}, the partition says {(int(rs[r]), int(cs[c]))}")
+    vals = np.concatenate([np.asfortranarray(m, np.float64).ravel(order="F") for m in mats]) if mats else np.zeros(0)
+    n = int(rs.sum())
+    rowptr = np.zeros(n + 1, np.int32)
+    col = np.zeros(max(vals.size, 1), np.int32)
+    val = np.zeros(max(vals.size, 1))
+    nnz = C.c_int64()
+    i32 = C.POINTER(C.c_int32)
+    _chk(lib().eigenex_solver_blocks_to_csr(rs.size, rs.ctypes.data_as(_lp), cs.size, cs.ctypes.data_as(_lp), len(keys),
+                                            qr.ctypes.data_as(_lp), qc.ctypes.data_as(_lp), _d(vals), rowptr.ctypes.data_as(i32),
+                                            col.ctypes.data_as(i32), _d(val), C.byref(nnz)))
     return rowptr, col[: nnz.value].copy(), val[: nnz.value].copy()
 
 

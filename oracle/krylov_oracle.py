@@ -702,3 +702,20 @@ def laplacian3d_eigenvalues(n: int, count: int):
     small = np.sort(c)[: min(n, 40)]
     s = (small[:, None, None] + small[None, :, None] + small[None, None, :]).ravel()
     return np.sort(s)[:count]
+
+
+def block_sparse_matmul(row_sizes, col_sizes, blocks):
+    """Operator of a reference BlockTensor<Scalar,2> H contracted with a rank-1 BlockTensor x over H's second
+    axis (block_tensor.hpp:1193-1206 storage, :2015-2055 contraction): stored blocks are visited in map order
+    (lexicographic {q_r, q_c}); each contributes the dense product B x_{q_c} to the rows of block q_r."""
+    ro = np.concatenate([[0], np.cumsum(row_sizes)])
+    co = np.concatenate([[0], np.cumsum(col_sizes)])
+    items = sorted(blocks.items())
+
+    def matmul(x):
+        y = np.zeros(ro[-1], dtype=np.result_type(x.dtype, *(b.dtype for _, b in items)))
+        for (qr, qc), B in items:
+            y[ro[qr]:ro[qr + 1]] += B @ x[co[qc]:co[qc + 1]]
+        return y
+
+    return matmul

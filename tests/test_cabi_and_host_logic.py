@@ -185,3 +185,28 @@ def test_triplets_to_csr_and_gershgorin(built):
     # all-negative discs: lowest() instead of the reference's numeric_limits::min() (documented deviation)
     lo, hi = solver.gershgorin_range(2, [0, 1], [0, 1], np.array([-3.0, -5.0]))
     assert (lo, hi) == (-5.0, -3.0)
+
+
+def test_blocks_to_csr_matches_blocktensor_contraction(built):
+    """Block-sparse ingestion (reference BlockTensor<S,2> storage block_tensor.hpp:1193-1206, contraction
+    :2015-2055): flattened CSR == the oracle's block-by-block contraction; ragged and empty blocks, repeated
+    block indices accumulate (addBlock)."""
+    _, solver = built
+    from oracle import krylov_oracle as ko
+
+    rng = np.random.default_rng(8)
+    rs, cs = [3, 0, 5, 1, 7], [2, 6, 0, 4]
+    blocks = {(qr, qc): rng.standard_normal((rs[qr], cs[qc])) for qr in range(5) for qc in range(4) if rng.random() < 0.6}
+    rowptr, col, val = solver.blocks_to_csr(rs, cs, blocks)
+    assert rowptr.size == sum(rs) + 1 and rowptr[-1] == sum(b.size for b in blocks.values())
+    for r in range(sum(rs)):
+        assert np.all(np.diff(col[rowptr[r]:rowptr[r + 1]]) > 0)
+    x = rng.standard_normal(sum(cs))
+    y = np.array([val[rowptr[r]:rowptr[r + 1]] @ x[col[rowptr[r]:rowptr[r + 1]]] for r in range(sum(rs))])
+    np.testing.assert_allclose(y, ko.block_sparse_matmul(rs, cs, blocks)(x), atol=1e-13)
+    # duplicates of one block index are summed
+    B = rng.standard_normal((3, 2))
+    _, _, v2 = solver.blocks_to_csr([3], [2], [((0, 0), B), ((0, 0), 2 * B)])
+    np.testing.assert_allclose(v2.reshape(3, 2), 3 * B)
+    with pytest.raises(Exception):
+        solver.blocks_to_csr([3], [2], {(0, 0): np.zeros((2, 2))})

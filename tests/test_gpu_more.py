@@ -109,3 +109,50 @@ def test_arnoldi_convergence_driven_continue_and_deflation(mods):
     np.testing.assert_allclose(r["hessenberg"], ref.hessenberg_matrix, atol=1e-10)
     assert np.abs(Q @ r["eigenvectors"]).max() < 1e-9
     ctx.close()
+
+
+def test_block_sparse_operator_config5_shape(mods):
+    """BASELINE config 5's ingredients at a size the oracle finishes quickly: a block-sparse symmetric
+    "Hamiltonian" in the reference's BlockTensor<double,2> layout as device operator (sharded), thick-restart
+    Lanczos m = 32; oracle = the BlockTensor contraction restated in numpy + the thick-restart oracle."""
+    capi, solver = mods
+    from oracle.thick_restart_oracle import thick_restart_lanczos
+
+    rng = np.random.default_rng(55)
+    sizes = [int(s) for s in rng.integers(3, 40, 60)]
+    nb = len(sizes)
+    blocks = {}
+    for q in range(nb):  # symmetric: diagonal blocks symmetric, off-diagonal pairs transposed
+        D = rng.standard_normal((sizes[q], sizes[q]))
+        blocks[(q, q)] = (D + D.T) / 2 + 2.0 * q / nb * np.eye(sizes[q])
+        for p in rng.choice(nb, 3, replace=False):
+            if p > q:
+                B = 0.3 * rng.standard_normal((sizes[q], sizes[p]))
+                blocks[(q, int(p))] = B
+                blocks[(int(p), q)] = B.T.copy()
+    N = sum(sizes)
+    matmul = ko.block_sparse_matmul(sizes, sizes, blocks)
+    rowptr, col, val = solver.blocks_to_csr(sizes, sizes, blocks)
+    assert rowptr[-1] == sum(b.size for b in blocks.values())
+    x = rng.standard_normal(N)
+    np.testing.assert_allclose(cref.csr_spmv(rowptr, col, val, x), matmul(x), atol=1e-12)
+    init = rng.standard_normal(N)
+    ref = thick_restart_lanczos(matmul, N, init, 4, 32, tol=1e-10)
+    ctx = capi.Context(loopback_shards=4)
+    A = capi.Csr.upload(ctx, N, rowptr, col, val)
+    es = solver.ThickRestartLanczosEigenSolver()
+    es.setDeviceOperator(A).set(numberOfEigenvalues=4, maxBasisSize=32, tolerance=1e-10, initialVector=init)
+    es.compute()
+    r = es.results()
+    dense = np.zeros((N, N))
+    ro = np.concatenate([[0], np.cumsum(sizes)])
+    for (qr, qc), B in blocks.items():
+        dense[ro[qr]:ro[qr + 1], ro[qc]:ro[qc + 1]] = B
+    lam = np.linalg.eigvalsh(dense)
+    scale = lam[-1] - lam[0]
+    assert r["info_name"] == "Success"
+    np.testing.assert_allclose(r["eigenvalues"], lam[:4], rtol=0, atol=1e-8 * scale)
+    np.testing.assert_allclose(r["eigenvalues"], ref["eigenvalues"], rtol=0, atol=1e-9 * scale)
+    for e in range(4):
+        assert np.linalg.norm(dense @ r["eigenvectors"][:, e] - r["eigenvalues"][e] * r["eigenvectors"][:, e]) < 1e-7 * scale
+    ctx.close()
