@@ -290,8 +290,8 @@ class Basis:
         self._cb = MATVEC_FN(tramp)
         _chk(lib().eigenex_basis_set_host_operator(self.h, self._cb, None))
 
-    def tune(self, vec_blocks_per_cu=2, spmv_blocks_per_cu=4, spmv_xcd_aware=0):
-        _chk(lib().eigenex_basis_tune(self.h, vec_blocks_per_cu, spmv_blocks_per_cu, spmv_xcd_aware))
+    def tune(self, vec_blocks_per_cu=2, spmv_blocks_per_cu=4, flags=0):
+        _chk(lib().eigenex_basis_tune(self.h, vec_blocks_per_cu, spmv_blocks_per_cu, flags))
 
     def clear(self):
         _chk(lib().eigenex_basis_clear(self.h))

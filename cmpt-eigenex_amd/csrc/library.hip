@@ -1150,13 +1150,13 @@ int eigenex_basis_create_ex(eigenex_context_t c, eigenex_csr_t csr, int64_t n_gl
   return 0;
 }
 
-int eigenex_basis_tune(eigenex_basis_t b, int vec_blocks_per_cu, int spmv_blocks_per_cu, int spmv_xcd_aware) {
+int eigenex_basis_tune(eigenex_basis_t b, int vec_blocks_per_cu, int spmv_blocks_per_cu, int flags) {
   if (!b || vec_blocks_per_cu < 1 || vec_blocks_per_cu > kMaxBlocksPerCu || spmv_blocks_per_cu < 1 || spmv_blocks_per_cu > kMaxBlocksPerCu)
     return fail(EIGENEX_ERR_ARG, "eigenex_basis_tune: blocks per CU must be in [1, 16]");
   for (auto& s : b->sh) {
     s.g_vec = grid_for_tiles((s.nd + kTileRows - 1) / kTileRows, vec_blocks_per_cu);
     s.g_spmv = grid_for_tiles((s.nloc + kSpmvRows - 1) / kSpmvRows, spmv_blocks_per_cu);
-    s.xcd_aware = spmv_xcd_aware & 3;  // bit 0: XCD-contiguous tiles, bit 1: non-temporal val/col loads
+    s.xcd_aware = flags & 3;  // bit 0: XCD-contiguous tiles, bit 1: non-temporal val/col loads
   }
   return 0;
 }

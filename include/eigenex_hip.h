@@ -161,9 +161,11 @@ int eigenex_basis_configure_z(eigenex_basis_t b, double shift_re, double shift_i
 int eigenex_basis_reserve(eigenex_basis_t b, int capacity);
 int eigenex_basis_capacity(eigenex_basis_t b, int* capacity);
 /* tuning knobs: workgroups per CU of the persistent grids (slab kernels dots/update, SpMV; 1..16, defaults 2 and 4)
- * and an XCD-contiguous tile order of the SpMV (default off: measured 7 % slower on the 512^3 stencil).  Results do not depend on them beyond the summation
- * order of the per-workgroup partial sums. */
-int eigenex_basis_tune(eigenex_basis_t b, int vec_blocks_per_cu, int spmv_blocks_per_cu, int spmv_xcd_aware);
+ * and `flags`, a bit set (default 0):
+ *   bit 0  XCD-contiguous tile order of the SpMV (measured 7 % slower on the 512^3 stencil)
+ *   bit 1  non-temporal loads of the CSR value/column streams (+5 % on a random 32-per-row CSR, slower on stencils)
+ * Results do not depend on the knobs beyond the summation order of the per-workgroup partial sums. */
+int eigenex_basis_tune(eigenex_basis_t b, int vec_blocks_per_cu, int spmv_blocks_per_cu, int flags);
 /* clearLanczosSteps()/clearArnoldiSteps(): forget vectors and coefficients, keep settings */
 int eigenex_basis_clear(eigenex_basis_t b);
 
