@@ -70,6 +70,8 @@ SIGNATURES = {
     "eigenex_csr_upload_z": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int64, _ip, _ip, _dp, C.POINTER(_vp)]),
     "eigenex_csr_laplacian3d": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp)]),
     "eigenex_csr_destroy": (C.c_int, [_vp]),
+    "eigenex_csr_upload_ex": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int64, _ip, _ip, _dp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "eigenex_csr_column_blocks": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "eigenex_csr_info": (C.c_int, [_vp, _lp, _lp, _lp, _lp]),
     "eigenex_basis_create": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.POINTER(_vp)]),
     "eigenex_basis_create_ex": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
@@ -211,17 +213,21 @@ class Csr:
         self.ctx, self.h = ctx, handle
 
     @classmethod
-    def upload(cls, ctx: Context, n_global: int, rowptr, col, val, row_begin: int = 0):
-        """val real (float64) or complex (complex128: uploaded as interleaved pairs, eigenex_csr_upload_z)."""
+    def upload(cls, ctx: Context, n_global: int, rowptr, col, val, row_begin: int = 0, column_blocks: int | None = None):
+        """val real (float64) or complex (complex128: uploaded as interleaved pairs, eigenex_csr_upload_z).
+        column_blocks: None = the plain entry points (automatic choice), else eigenex_csr_upload_ex's argument."""
         rp = np.ascontiguousarray(rowptr, np.int32)
         cl = np.ascontiguousarray(col, np.int32)
         h = _vp()
-        if np.iscomplexobj(val):
-            vl = np.ascontiguousarray(val, np.complex128)
-            _chk(lib().eigenex_csr_upload_z(ctx.h, n_global, row_begin, rp.size - 1, _i(rp), _i(cl), _d(vl.view(np.float64)), C.byref(h)))
+        cplx = bool(np.iscomplexobj(val))
+        vl = np.ascontiguousarray(val, np.complex128 if cplx else np.float64)
+        vp = _d(vl.view(np.float64))
+        if column_blocks is not None:
+            _chk(lib().eigenex_csr_upload_ex(ctx.h, n_global, row_begin, rp.size - 1, _i(rp), _i(cl), vp, int(cplx), int(column_blocks), C.byref(h)))
+        elif cplx:
+            _chk(lib().eigenex_csr_upload_z(ctx.h, n_global, row_begin, rp.size - 1, _i(rp), _i(cl), vp, C.byref(h)))
         else:
-            vl = np.ascontiguousarray(val, np.float64)
-            _chk(lib().eigenex_csr_upload(ctx.h, n_global, row_begin, rp.size - 1, _i(rp), _i(cl), _d(vl), C.byref(h)))
+            _chk(lib().eigenex_csr_upload(ctx.h, n_global, row_begin, rp.size - 1, _i(rp), _i(cl), vp, C.byref(h)))
         obj = cls(ctx, h)
         obj.is_complex = bool(np.iscomplexobj(val))
         return obj
@@ -231,6 +237,11 @@ class Csr:
         h = _vp()
         _chk(lib().eigenex_csr_laplacian3d(ctx.h, n, C.byref(h)))
         return cls(ctx, h)
+
+    def column_blocks(self) -> int:
+        k = C.c_int()
+        _chk(lib().eigenex_csr_column_blocks(self.h, C.byref(k)))
+        return k.value
 
     def info(self):
         v = [C.c_int64() for _ in range(4)]

@@ -389,7 +389,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int32_t* __restrict__ row
                                                  const double* __restrict__ scale_ptr, double shift,
                                                  double* __restrict__ y, double* __restrict__ u_out, int64_t n,
                                                  int64_t ntiles, double* __restrict__ partials, int xcd_aware,
-                                                 const Ctrl* __restrict__ ctrl) {
+                                                 int pass, const Ctrl* __restrict__ ctrl) {
   __shared__ double prod[kSpmvChunk + kSpmvChunk / 32 + 8];
   __shared__ double lds4[4];
   if (ctrl->stopped) return;
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int32_t* __restrict__ row
     int nrs, nre, np0, np1;
     tile_rows(tile + tr.step, nrs, nre, np0, np1);
     const int pa = p0 & ~3;  // aligned start: int4 / double2 loads
-    double sum = 0.0;
+    double sum = ((pass & kPassCarry) && r < n) ? y[r] : 0.0;  // column-blocked: carry the row sum from pass to pass
     for (int cb = pa; cb < p1; cb += kSpmvChunk) {
       const int cend = (cb + kSpmvChunk < p1) ? cb + kSpmvChunk : p1;
       // phase 1: a chunk is two rounds of 4 entries per lane; all six 16-byte loads are issued before
@@ -477,7 +477,9 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int32_t* __restrict__ row
       for (int p = lo; p < hi; ++p) sum = sum + prod[skew(p - cb)];
       __syncthreads();
     }
-    if (r < n) {
+    if ((pass & kPassNotLast) && r < n) {
+      y[r] = sum;
+    } else if (r < n) {
       const double xr = x_ext[r] * scale;
       double yr = sum;
       if (shift != 0.0) yr = yr + shift * xr;  // lanczos.hpp:390-392
@@ -515,7 +517,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_z(const int32_t* __restrict__ r
                                                    double shift_im, double2* __restrict__ y,
                                                    double2* __restrict__ u_out, int64_t n, int64_t ntiles,
                                                    double* __restrict__ partials, int pstride, int xcd_aware,
-                                                   const Ctrl* __restrict__ ctrl) {
+                                                   int pass, const Ctrl* __restrict__ ctrl) {
   __shared__ double2 prod[kSpmvChunkZ + kSpmvChunkZ / 16 + 8];
   __shared__ double lds4[4];
   if (ctrl->stopped) return;
@@ -536,7 +538,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_z(const int32_t* __restrict__ r
     const int p0 = rowptr[r0];
     const int p1 = rowptr[rend];
     const int pa = p0 & ~3;
-    double2 sum = make_double2(0.0, 0.0);
+    double2 sum = ((pass & kPassCarry) && r < n) ? y[r] : make_double2(0.0, 0.0);
     for (int cb = pa; cb < p1; cb += kSpmvChunkZ) {
       const int cend = (cb + kSpmvChunkZ < p1) ? cb + kSpmvChunkZ : p1;
       for (int q = cb + 4 * tid; q < cend; q += 4 * kBlock) {
@@ -561,7 +563,9 @@ __global__ __launch_bounds__(kBlock) void k_spmv_z(const int32_t* __restrict__ r
       }
       __syncthreads();
     }
-    if (r < n) {
+    if ((pass & kPassNotLast) && r < n) {
+      y[r] = sum;
+    } else if (r < n) {
       double2 xr = x_ext[r];
       xr.x *= scale;
       xr.y *= scale;
@@ -958,11 +962,11 @@ void launch_update(hipStream_t s, const double* src, double* dst, ThreeTerm tt, 
 
 void launch_spmv_z(hipStream_t s, const int32_t* rowptr, const int32_t* col, const double* val, const double* x_ext,
                    const double* scale, double shift_re, double shift_im, double* y, double* u_out, int64_t n,
-                   double* partials, int pstride, int grid, const Ctrl* ctrl, int xcd_aware) {
+                   double* partials, int pstride, int grid, const Ctrl* ctrl, int xcd_aware, int pass) {
   const int64_t ntiles = (n + kSpmvRows - 1) / kSpmvRows;
   hipLaunchKernelGGL(k_spmv_z, dim3(grid), dim3(kBlock), 0, s, rowptr, col, reinterpret_cast<const double2*>(val),
                      reinterpret_cast<const double2*>(x_ext), scale, shift_re, shift_im, reinterpret_cast<double2*>(y),
-                     reinterpret_cast<double2*>(u_out), n, ntiles, partials, pstride, xcd_aware, ctrl);
+                     reinterpret_cast<double2*>(u_out), n, ntiles, partials, pstride, xcd_aware, pass, ctrl);
 }
 
 void launch_shift_dot_z(hipStream_t s, double* y, const double* u, double shift_re, double shift_im, int64_t n,
@@ -979,10 +983,10 @@ void launch_reduce(hipStream_t s, const double* partials, int pstride, int nbloc
 
 void launch_spmv(hipStream_t s, const int32_t* rowptr, const int32_t* col, const double* val, const double* x_ext,
                  const double* scale, double shift, double* y, double* u_out, int64_t n, double* partials, int grid,
-                 const Ctrl* ctrl, int xcd_aware) {
+                 const Ctrl* ctrl, int xcd_aware, int pass) {
   const int64_t ntiles = (n + kSpmvRows - 1) / kSpmvRows;
   hipLaunchKernelGGL(k_spmv, dim3(grid), dim3(kBlock), 0, s, rowptr, col, val, x_ext, scale, shift, y, u_out, n,
-                     ntiles, partials, xcd_aware, ctrl);
+                     ntiles, partials, xcd_aware, pass, ctrl);
 }
 
 void launch_scale(hipStream_t s, const double* x, const double* scale_dev, double scale_host, double* out, int64_t n,

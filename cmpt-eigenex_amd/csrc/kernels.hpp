@@ -56,16 +56,19 @@ void launch_update(hipStream_t s, const double* src, double* dst, ThreeTerm tt, 
 // complex operator: n = rows; val/x/y/u_out interleaved (re, im); partials[block] = re, partials[pstride+block] = im of conj(u).y
 void launch_spmv_z(hipStream_t s, const int32_t* rowptr, const int32_t* col, const double* val, const double* x_ext,
                    const double* scale, double shift_re, double shift_im, double* y, double* u_out, int64_t n,
-                   double* partials, int pstride, int grid, const Ctrl* ctrl, int xcd_aware = 1);
+                   double* partials, int pstride, int grid, const Ctrl* ctrl, int xcd_aware = 1, int pass = 0);
 void launch_shift_dot_z(hipStream_t s, double* y, const double* u, double shift_re, double shift_im, int64_t n,
                         double* partials, int pstride, int grid, const Ctrl* ctrl);
 // out[c] = sum_b partials[c*pstride + b], fixed order (deterministic second stage)
 void launch_reduce(hipStream_t s, const double* partials, int pstride, int nblocks, int ncols, double* out,
                    const Ctrl* ctrl);
 // y = A*(x*scale) + shift*(x*scale); u_out = x*scale (optional); partials[block] = partial (x*scale).y (optional)
+// Column-blocked operators run one launch per pass: `pass` bit 0 (kPassCarry) = the row sums start from y (left by
+// the previous pass), bit 1 (kPassNotLast) = store the raw row sums only (no shift, u_out, dot).
+enum { kPassCarry = 1, kPassNotLast = 2 };
 void launch_spmv(hipStream_t s, const int32_t* rowptr, const int32_t* col, const double* val, const double* x_ext,
                  const double* scale, double shift, double* y, double* u_out, int64_t n, double* partials, int grid,
-                 const Ctrl* ctrl, int xcd_aware = 1);
+                 const Ctrl* ctrl, int xcd_aware = 1, int pass = 0);
 // host-operator path: u_out = x*scale
 void launch_scale(hipStream_t s, const double* x, const double* scale_dev, double scale_host, double* out, int64_t n,
                   const Ctrl* ctrl);

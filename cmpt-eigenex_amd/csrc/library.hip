@@ -154,6 +154,8 @@ struct CsrShard {
   int gshard = 0;
   int64_t rb = 0, re = 0, nloc = 0, npad = 0, nnz = 0, nhalo = 0;
   int es = 1;  // doubles per stored value: 1 real, 2 complex (re, im interleaved)
+  int passes = 1;  // column-blocked: entries grouped by pass, rowptr holds `passes` row-pointer arrays of nloc+1
+                   // absolute offsets each (see choose_column_blocks)
   int32_t* rowptr = nullptr;
   int32_t* col = nullptr;
   double* val = nullptr;
@@ -331,8 +333,64 @@ int finish_send(eigenex_context_s* c, CsrShard& s, const std::vector<int32_t>& i
 }
 
 // Host-side shard construction from user CSR arrays (global columns).
+// Column blocking (include/eigenex_hip.h, eigenex_csr_upload_ex).  Slices are cut in GLOBAL column order --
+// halo columns below the shard, local columns, halo columns above -- so that a row with ascending global
+// columns meets them in pass order.  Returns the number of passes and fills blk[p] (pass of stored entry p).
+constexpr int kMaxColumnBlocks = 16;
+constexpr int64_t kSliceBytes = 2 << 20;  // half of one XCD's 4 MB L2: the rest is left to the val/col streams
+
+int choose_column_blocks(const CsrShard& s, const std::vector<int32_t>& lcol, const std::vector<int32_t>& lrp, int request,
+                         std::vector<uint8_t>& blk) {
+  if (request == 0 || request == 1 || s.nnz == 0 || s.nloc == 0) return 1;
+  const int64_t ext = s.nloc + s.nhalo;
+  int K = request;
+  if (request < 0) {
+    const int64_t need = (ext * 8 * s.es + kSliceBytes - 1) / kSliceBytes;
+    const int64_t avg = s.nnz / s.nloc;
+    K = (int)std::min<int64_t>(std::min<int64_t>(need, avg / 6), 8);
+    if (K < 2) return 1;
+    // scattered gathers?  sample row tiles: distinct 128-byte lines of the operator input per stored entry
+    int64_t entries = 0, lines = 0;
+    std::vector<int32_t> tmp;
+    for (int64_t r0 = 0; r0 < s.nloc; r0 += 256 * 61) {
+      const int64_t r1 = std::min<int64_t>(r0 + 256, s.nloc);
+      tmp.assign(lcol.begin() + lrp[r0], lcol.begin() + lrp[r1]);
+      for (auto& x : tmp) x = (int32_t)(((int64_t)x * s.es) >> 4);
+      std::sort(tmp.begin(), tmp.end());
+      entries += (int64_t)tmp.size();
+      lines += std::unique(tmp.begin(), tmp.end()) - tmp.begin();
+    }
+    if (entries == 0 || 2 * lines < entries) return 1;
+  }
+  K = std::min(K, kMaxColumnBlocks);
+  const int64_t n_low = std::lower_bound(s.halo_cols.begin(), s.halo_cols.end(), (int32_t)std::min<int64_t>(s.rb, 2147483647)) -
+                        s.halo_cols.begin();
+  const int64_t W = (ext + K - 1) / K;
+  blk.resize((size_t)s.nnz);
+  bool in_order = true;
+  for (int64_t i = 0; i < s.nloc; ++i) {
+    int prev = 0;
+    for (int64_t p = lrp[i]; p < lrp[i + 1]; ++p) {
+      const int64_t lc = lcol[p];
+      int64_t pos;
+      if (lc < s.npad) {
+        pos = n_low + lc;
+      } else {
+        const int64_t h = lc - s.npad;
+        pos = h < n_low ? h : s.nloc + h;
+      }
+      const int k = (int)(pos / W);
+      blk[p] = (uint8_t)k;
+      if (k < prev) in_order = false;
+      prev = k;
+    }
+  }
+  if (request < 0 && !in_order) return 1;  // automatic mode never changes a result
+  return K;
+}
+
 int build_shard_host(eigenex_context_s* c, int64_t n_global, int gshard, const int32_t* rowptr, const int32_t* col,
-                     const double* val, int es, CsrShard& s) {
+                     const double* val, int es, int column_blocks, CsrShard& s) {
   s.gshard = gshard;
   s.es = es;
   partition(n_global, c->P, gshard, &s.rb, &s.re);
@@ -363,13 +421,48 @@ int build_shard_host(eigenex_context_s* c, int64_t n_global, int gshard, const i
   }
   std::vector<int32_t> lrp((size_t)s.nloc + 1);
   for (int64_t i = 0; i <= s.nloc; ++i) lrp[i] = (int32_t)(rowptr[i] - p0);
-  HIPCHK(hipMalloc(&s.rowptr, sizeof(int32_t) * (s.nloc + 1)));
+  const double* vsrc = val + p0 * es;
+  std::vector<uint8_t> blk;
+  std::vector<double> bval;
+  s.passes = choose_column_blocks(s, lcol, lrp, column_blocks, blk);
+  if (s.passes > 1) {
+    // stable counting sort of the entries by (pass, row): pass k's entries are contiguous, rows keep stored order
+    const int K = s.passes;
+    const int64_t R = s.nloc + 1;
+    std::vector<int32_t> brp((size_t)K * R, 0), bcol((size_t)s.nnz + 8, 0);
+    bval.assign((size_t)(s.nnz + 8) * es, 0.0);
+    for (int64_t i = 0; i < s.nloc; ++i)
+      for (int64_t p = lrp[i]; p < lrp[i + 1]; ++p) brp[(size_t)blk[p] * R + i + 1]++;
+    int64_t run = 0;
+    for (int k = 0; k < K; ++k) {
+      brp[(size_t)k * R] = (int32_t)run;
+      for (int64_t i = 0; i < s.nloc; ++i) {
+        const int64_t cnt = brp[(size_t)k * R + i + 1];
+        brp[(size_t)k * R + i + 1] = (int32_t)(brp[(size_t)k * R + i] + cnt);
+      }
+      run = brp[(size_t)k * R + s.nloc];
+    }
+    std::vector<int32_t> cur((size_t)K);
+    for (int64_t i = 0; i < s.nloc; ++i) {
+      for (int k = 0; k < K; ++k) cur[k] = brp[(size_t)k * R + i];
+      for (int64_t p = lrp[i]; p < lrp[i + 1]; ++p) {
+        const int64_t q = cur[blk[p]]++;
+        bcol[q] = lcol[p];
+        for (int e = 0; e < es; ++e) bval[(size_t)q * es + e] = vsrc[(size_t)p * es + e];
+      }
+    }
+    lrp.swap(brp);
+    lcol.swap(bcol);
+    vsrc = bval.data();
+  }
+  const size_t nrp = (size_t)s.passes * (s.nloc + 1);
+  HIPCHK(hipMalloc(&s.rowptr, sizeof(int32_t) * nrp));
   HIPCHK(hipMalloc(&s.col, sizeof(int32_t) * (s.nnz + 8)));
   HIPCHK(hipMalloc(&s.val, sizeof(double) * (s.nnz + 8) * es));
   HIPCHK(hipMemsetAsync(s.val, 0, sizeof(double) * (s.nnz + 8) * es, c->stream));
-  HIPCHK(hipMemcpyAsync(s.rowptr, lrp.data(), sizeof(int32_t) * (s.nloc + 1), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(s.rowptr, lrp.data(), sizeof(int32_t) * nrp, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(s.col, lcol.data(), sizeof(int32_t) * (s.nnz + 8), hipMemcpyHostToDevice, c->stream));
-  if (s.nnz) HIPCHK(hipMemcpyAsync(s.val, val + p0 * es, sizeof(double) * s.nnz * es, hipMemcpyHostToDevice, c->stream));
+  if (s.nnz) HIPCHK(hipMemcpyAsync(s.val, vsrc, sizeof(double) * s.nnz * es, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   build_recv(s, n_global, c->P);
   return 0;
@@ -550,6 +643,23 @@ int enq_orthogonalize(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_t
   return 0;
 }
 
+// one operator application on one shard: a launch per column-block pass, the row sums carried in y
+void launch_operator(hipStream_t st, const CsrShard* m, int es, const double* x_ext, const double* scale, double shift,
+                     double shift_im, double* y, double* u_out, double* partials, int pstride, int grid, const Ctrl* ctrl,
+                     int flags) {
+  for (int k = 0; k < m->passes; ++k) {
+    const bool last = k == m->passes - 1;
+    const int pass = (k > 0 ? kPassCarry : 0) | (last ? 0 : kPassNotLast);
+    const int32_t* rp = m->rowptr + (int64_t)k * (m->nloc + 1);
+    if (es == 2)
+      launch_spmv_z(st, rp, m->col, m->val, x_ext, scale, shift, shift_im, y, u_out, m->nloc, last ? partials : nullptr, pstride,
+                    grid, ctrl, flags, pass);
+    else
+      launch_spmv(st, rp, m->col, m->val, x_ext, scale, shift, y, u_out, m->nloc, last ? partials : nullptr, grid, ctrl, flags,
+                  pass);
+  }
+}
+
 // v = (A + shift) * (w*scale), basis column `ucol` = w*scale, optional alpha = u.v -> hbuf[slot_alpha]
 // Returns 1 in *skipped if the device had already stopped (host-operator path only).
 int enq_apply(eigenex_basis_s* b, int ucol, bool want_dot) {
@@ -560,12 +670,8 @@ int enq_apply(eigenex_basis_s* b, int ucol, bool want_dot) {
       CsrShard* m = s.csr;
       {
         ProfScope ps(c, EIGENEX_K_SPMV, (4.0 + 8.0 * b->es) * m->nnz + 4.0 * (m->nloc + 1) + 32.0 * s.nd + (want_dot ? 16.0 * s.nd : 0.0));
-        if (b->es == 2)
-          launch_spmv_z(c->stream, m->rowptr, m->col, m->val, s.w, &s.ctrl->scale, b->shift, b->shift_im, s.v,
-                        s.V + (int64_t)ucol * s.ldd, s.nloc, want_dot ? s.partials : nullptr, s.pstride, s.g_spmv, s.ctrl, s.xcd_aware);
-        else
-          launch_spmv(c->stream, m->rowptr, m->col, m->val, s.w, &s.ctrl->scale, b->shift, s.v,
-                      s.V + (int64_t)ucol * s.ldd, s.nloc, want_dot ? s.partials : nullptr, s.g_spmv, s.ctrl, s.xcd_aware);
+        launch_operator(c->stream, m, b->es, s.w, &s.ctrl->scale, b->shift, b->shift_im, s.v, s.V + (int64_t)ucol * s.ldd,
+                        want_dot ? s.partials : nullptr, s.pstride, s.g_spmv, s.ctrl, s.xcd_aware);
       }
       if (want_dot) {
         ProfScope ps(c, EIGENEX_K_SMALL, 0.0);
@@ -896,7 +1002,8 @@ int eigenex_profile_get(eigenex_context_t c, int kind, int64_t* launches, double
 
 // ---- operator ---------------------------------------------------------------
 static int csr_upload_impl(eigenex_context_t c, int64_t n_global, int64_t row_begin, int64_t n_rows, const int32_t* rowptr,
-                           const int32_t* col_global, const double* val, int es, eigenex_csr_t* out) {
+                           const int32_t* col_global, const double* val, int es, int column_blocks, eigenex_csr_t* out) {
+  if (column_blocks < -1 || column_blocks > kMaxColumnBlocks) return fail(EIGENEX_ERR_ARG, "column_blocks must be in [-1, 16]");
   if (!c || !out || !rowptr || n_global <= 0 || n_rows < 0) return fail(EIGENEX_ERR_ARG, "eigenex_csr_upload: bad argument");
   if (n_rows > 0 && rowptr[n_rows] > rowptr[0] && (!col_global || !val)) return fail(EIGENEX_ERR_ARG, "col/val is NULL");
   HIPCHK(hipSetDevice(c->device));
@@ -914,7 +1021,7 @@ static int csr_upload_impl(eigenex_context_t c, int64_t n_global, int64_t row_be
   for (size_t i = 0; i < c->local.size() && !rc; ++i) {
     int64_t rb, re;
     partition(n_global, c->P, c->local[i], &rb, &re);
-    rc = build_shard_host(c, n_global, c->local[i], rowptr + (rb - row_begin), col_global, val, es, m->sh[i]);
+    rc = build_shard_host(c, n_global, c->local[i], rowptr + (rb - row_begin), col_global, val, es, column_blocks, m->sh[i]);
   }
   if (!rc && c->P > 1) rc = c->loopback ? build_send_lists_loopback(c, m) : exchange_send_lists_rccl(c, n_global, m->sh[0]);
   if (rc) {
@@ -929,12 +1036,24 @@ static int csr_upload_impl(eigenex_context_t c, int64_t n_global, int64_t row_be
 
 int eigenex_csr_upload(eigenex_context_t c, int64_t n_global, int64_t row_begin, int64_t n_rows, const int32_t* rowptr,
                        const int32_t* col_global, const double* val, eigenex_csr_t* out) {
-  return csr_upload_impl(c, n_global, row_begin, n_rows, rowptr, col_global, val, 1, out);
+  return csr_upload_impl(c, n_global, row_begin, n_rows, rowptr, col_global, val, 1, -1, out);
+}
+
+int eigenex_csr_upload_ex(eigenex_context_t c, int64_t n_global, int64_t row_begin, int64_t n_rows, const int32_t* rowptr,
+                          const int32_t* col_global, const double* val, int is_complex, int column_blocks, eigenex_csr_t* out) {
+  return csr_upload_impl(c, n_global, row_begin, n_rows, rowptr, col_global, val, is_complex ? 2 : 1, column_blocks, out);
+}
+
+int eigenex_csr_column_blocks(eigenex_csr_t m, int* passes) {
+  if (!m || !passes) return fail(EIGENEX_ERR_ARG, "eigenex_csr_column_blocks: NULL argument");
+  *passes = 1;
+  for (auto& s : m->sh) *passes = std::max(*passes, s.passes);
+  return 0;
 }
 
 int eigenex_csr_upload_z(eigenex_context_t c, int64_t n_global, int64_t row_begin, int64_t n_rows, const int32_t* rowptr,
                          const int32_t* col_global, const double* val_interleaved, eigenex_csr_t* out) {
-  return csr_upload_impl(c, n_global, row_begin, n_rows, rowptr, col_global, val_interleaved, 2, out);
+  return csr_upload_impl(c, n_global, row_begin, n_rows, rowptr, col_global, val_interleaved, 2, -1, out);
 }
 
 int eigenex_csr_laplacian3d(eigenex_context_t c, int64_t n, eigenex_csr_t* out) {
@@ -1306,12 +1425,8 @@ int eigenex_apply(eigenex_basis_t b, int x_ref, int y_ref, double shift, double*
   for (auto& s : b->sh) {
     CsrShard* m = s.csr;
     ProfScope ps(c, EIGENEX_K_SPMV, (4.0 + 8.0 * b->es) * m->nnz + 4.0 * (m->nloc + 1) + 16.0 * s.nd);
-    if (b->es == 2)
-      launch_spmv_z(c->stream, m->rowptr, m->col, m->val, s.w, nullptr, shift, 0.0, vec_ptr(s, b->cap, b->nq, y_ref), nullptr,
-                    s.nloc, dot ? s.partials : nullptr, s.pstride, s.g_spmv, s.ctrl_zero);
-    else
-      launch_spmv(c->stream, m->rowptr, m->col, m->val, s.w, nullptr, shift, vec_ptr(s, b->cap, b->nq, y_ref), nullptr,
-                  s.nloc, dot ? s.partials : nullptr, s.g_spmv, s.ctrl_zero);
+    launch_operator(c->stream, m, b->es, s.w, nullptr, shift, 0.0, vec_ptr(s, b->cap, b->nq, y_ref), nullptr,
+                    dot ? s.partials : nullptr, s.pstride, s.g_spmv, s.ctrl_zero, s.xcd_aware);
     if (dot) launch_reduce(c->stream, s.partials, s.pstride, s.g_spmv, b->es, s.hbuf + b->slot_alpha(), s.ctrl_zero);
   }
   if (dot) {

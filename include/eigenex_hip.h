@@ -132,6 +132,20 @@ int eigenex_csr_upload(eigenex_context_t ctx, int64_t n_global, int64_t row_begi
 int eigenex_csr_upload_z(eigenex_context_t ctx, int64_t n_global, int64_t row_begin, int64_t n_rows,
                          const int32_t* rowptr, const int32_t* col_global, const double* val_interleaved,
                          eigenex_csr_t* out);
+/* Upload with an explicit column-blocking choice.  A column-blocked operator is applied in K passes, pass k
+ * holding the entries whose column lies in the k-th slice of the operator input, so that a slice (<= ~2 MB) stays
+ * in each XCD's L2 while it is gathered from: 1.5x on a random 32-per-row matrix of 10^6 rows (BASELINE config 3),
+ * useless for stencils.  Each row's running sum is carried from pass to pass, so the result is bit-identical to
+ * the single-pass row loop whenever the slices are met in stored order along every row (always true for rows
+ * with ascending columns); otherwise the entries of a row are added slice by slice (rounding-level difference).
+ *   column_blocks = -1  automatic (what eigenex_csr_upload[_z] do): block only if the input vector exceeds L2,
+ *                       rows are long enough, the gathers are scattered, and the result stays bit-identical
+ *   column_blocks = 0,1 never;  2..16: that many passes, unconditionally */
+int eigenex_csr_upload_ex(eigenex_context_t ctx, int64_t n_global, int64_t row_begin, int64_t n_rows,
+                          const int32_t* rowptr, const int32_t* col_global, const double* val, int is_complex,
+                          int column_blocks, eigenex_csr_t* out);
+/* passes of the (largest) local shard: 1 = not column-blocked */
+int eigenex_csr_column_blocks(eigenex_csr_t csr, int* passes);
 /* synthetic 7-point Laplacian on an n^3 grid generated on the device (BASELINE configs 2 and 4) */
 int eigenex_csr_laplacian3d(eigenex_context_t ctx, int64_t n, eigenex_csr_t* out);
 int eigenex_csr_destroy(eigenex_csr_t csr);

@@ -1,4 +1,4 @@
-"""In-process A/B of SpMV knobs on BASELINE config 3 (random CSR, N rows, 32/row): usage python scripts/ab_arnoldi.py N m rounds "vec,spmv,flags;..." """
+"""In-process A/B of SpMV knobs on BASELINE config 3 (random CSR, N rows, 32/row): usage python scripts/ab_arnoldi.py N m rounds "vec,spmv,flags;..." [column_blocks] """
 import sys, time
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np
@@ -7,7 +7,9 @@ from test_gpu_fullsize import _random_csr32
 N, m, rounds = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 variants = [tuple(int(x) for x in v.split(",")) for v in sys.argv[4].split(";")]
 rowptr, col, val = _random_csr32(N, 12345)
-ctx = capi.Context(); A = capi.Csr.upload(ctx, N, rowptr, col, val); b = capi.Basis(ctx, A, N, m)
+K = int(sys.argv[5]) if len(sys.argv) > 5 else None
+ctx = capi.Context(); A = capi.Csr.upload(ctx, N, rowptr, col, val, column_blocks=K); b = capi.Basis(ctx, A, N, m)
+print("column blocks:", A.column_blocks())
 b.upload(capi.VEC_START, np.random.default_rng(0).standard_normal(N))
 res = {v: [] for v in variants}
 for r in range(rounds + 1):
