@@ -793,50 +793,58 @@ __global__ __launch_bounds__(kBlock) void k_laplacian3d(int64_t n, int64_t rb, i
 }
 
 // ---- Ritz vectors: X = V * S, up to 8 columns per pass over V ----------------
-constexpr int kRitzCols = 8;
+// NE output columns per pass over the basis, 4 rows (2 x double2) per thread and column, the m loop unrolled so
+// that 8 independent 16-byte loads are in flight per lane.  St is the coefficient block of this pass, packed
+// [nvec][NE] (zero-padded behind nev) so that the NE coefficients of one basis column are one scalar load burst.
+// Rows behind n inside the padded column stride are zero in V and are written back as zeros.
+template <int NE, bool NORM>
 __global__ __launch_bounds__(kBlock) void k_ritz(const double* __restrict__ V, int64_t ldv, int nvec,
-                                                 const double* __restrict__ S, int lds_, int nev,
-                                                 double* __restrict__ X, int64_t ldx, int64_t n, int64_t ntiles,
-                                                 double* __restrict__ partials, int pstride) {
+                                                 const double* __restrict__ St, int nev, double* __restrict__ X,
+                                                 int64_t ldx, int64_t n, int64_t ntiles, double* __restrict__ partials,
+                                                 int pstride) {
   __shared__ double lds4[4];
-  double nrm[kRitzCols];
+  constexpr int kRows = 4 * kBlock;  // rows per tile
+  double nrm[NE];
 #pragma unroll
-  for (int e = 0; e < kRitzCols; ++e) nrm[e] = 0.0;
+  for (int e = 0; e < NE; ++e) nrm[e] = 0.0;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t base = tile * (2 * kBlock) + 2 * threadIdx.x;  // 512 rows per tile
-    if (base >= n) continue;
-    double2 acc[kRitzCols];
+    const int64_t r0 = tile * kRows + 2 * threadIdx.x, r1 = r0 + 2 * kBlock;
+    const bool in0 = r0 < n, in1 = r1 < n;
+    double2 a0[NE], a1[NE];
 #pragma unroll
-    for (int e = 0; e < kRitzCols; ++e) acc[e] = make_double2(0.0, 0.0);
-    for (int m = 0; m < nvec; ++m) {
-      const double2 v = ld2(V + (int64_t)m * ldv + base);
+    for (int e = 0; e < NE; ++e) a0[e] = a1[e] = make_double2(0.0, 0.0);
+    const double* vp = V;
+#pragma unroll 4
+    for (int m = 0; m < nvec; ++m, vp += ldv) {
+      const double2 v0 = in0 ? ld2(vp + r0) : make_double2(0.0, 0.0);
+      const double2 v1 = in1 ? ld2(vp + r1) : make_double2(0.0, 0.0);
+      const double* sp = St + (int64_t)m * NE;
 #pragma unroll
-      for (int e = 0; e < kRitzCols; ++e) {
-        if (e < nev) {
-          const double s = S[m + (int64_t)e * lds_];
-          acc[e].x = fma(s, v.x, acc[e].x);  // lanczos.hpp:802-804 (m ascending)
-          acc[e].y = fma(s, v.y, acc[e].y);
-        }
+      for (int e = 0; e < NE; ++e) {
+        const double c = sp[e];
+        a0[e].x = fma(c, v0.x, a0[e].x);  // lanczos.hpp:802-804 (m ascending)
+        a0[e].y = fma(c, v0.y, a0[e].y);
+        a1[e].x = fma(c, v1.x, a1[e].x);
+        a1[e].y = fma(c, v1.y, a1[e].y);
       }
     }
 #pragma unroll
-    for (int e = 0; e < kRitzCols; ++e) {
+    for (int e = 0; e < NE; ++e) {
       if (e < nev) {
-        double* xp = X + (int64_t)e * ldx + base;
-        xp[0] = acc[e].x;
-        nrm[e] = fma(acc[e].x, acc[e].x, nrm[e]);
-        if (base + 1 < n) {
-          xp[1] = acc[e].y;
-          nrm[e] = fma(acc[e].y, acc[e].y, nrm[e]);
-        }
+        double* xp = X + (int64_t)e * ldx;
+        if (in0) st2(xp + r0, a0[e]);
+        if (in1) st2(xp + r1, a1[e]);
+        if (NORM) nrm[e] = fma(a0[e].x, a0[e].x, fma(a0[e].y, a0[e].y, fma(a1[e].x, a1[e].x, fma(a1[e].y, a1[e].y, nrm[e]))));
       }
     }
   }
+  if (NORM) {
 #pragma unroll
-  for (int e = 0; e < kRitzCols; ++e) {
-    if (e < nev) {
-      const double s = block_sum(nrm[e], lds4);
-      if (threadIdx.x == 0) partials[(int64_t)e * pstride + blockIdx.x] = s;
+    for (int e = 0; e < NE; ++e) {
+      if (e < nev) {
+        const double t = block_sum(nrm[e], lds4);
+        if (threadIdx.x == 0) partials[(int64_t)e * pstride + blockIdx.x] = t;
+      }
     }
   }
 }
@@ -1049,11 +1057,13 @@ void launch_laplacian3d(hipStream_t s, int64_t n, int64_t rb, int64_t re, int64_
                      col, val);
 }
 
-void launch_ritz(hipStream_t s, const double* V, int64_t ldv, int nvec, const double* S_dev, int lds, int nev,
+void launch_ritz(hipStream_t s, const double* V, int64_t ldv, int nvec, const double* St_dev, int ne_pack, int nev,
                  double* X, int64_t ldx, int64_t n, double* partials, int pstride, int grid) {
-  const int64_t ntiles = (n + 2 * kBlock - 1) / (2 * kBlock);
-  hipLaunchKernelGGL(k_ritz, dim3(grid), dim3(kBlock), 0, s, V, ldv, nvec, S_dev, lds, nev, X, ldx, n, ntiles,
-                     partials, pstride);
+  const int64_t ntiles = (n + 4 * kBlock - 1) / (4 * kBlock);
+  if (ne_pack == 16)
+    hipLaunchKernelGGL((k_ritz<16, false>), dim3(grid), dim3(kBlock), 0, s, V, ldv, nvec, St_dev, nev, X, ldx, n, ntiles, partials, pstride);
+  else
+    hipLaunchKernelGGL((k_ritz<8, true>), dim3(grid), dim3(kBlock), 0, s, V, ldv, nvec, St_dev, nev, X, ldx, n, ntiles, partials, pstride);
 }
 
 void launch_first_nonzero(hipStream_t s, const double* X, int64_t ldx, int ncol, int64_t n, int es, double* out) {

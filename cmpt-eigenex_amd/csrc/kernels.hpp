@@ -107,8 +107,11 @@ void launch_accept_vector(hipStream_t s, Ctrl* ctrl);
 void launch_laplacian3d(hipStream_t s, int64_t n, int64_t rb, int64_t re, int64_t lower_start, int64_t n_lower,
                         int64_t halo_base, int32_t* rowptr, int32_t* col, double* val);
 
-// Ritz vectors: X[:, e] = sum_m S[m + e*lds] * V[:, m]  for e < nev (<= 8 per launch); partial norms
-void launch_ritz(hipStream_t s, const double* V, int64_t ldv, int nvec, const double* S_dev, int lds, int nev,
+// Ritz vectors / basis compression: X[:, e] = sum_m St[m*ne_pack + e] * V[:, m] for e < nev <= ne_pack; St is the
+// coefficient block packed [nvec][ne_pack], zero-padded.  ne_pack = 8: also partial squared norms of the results
+// (partials[e*pstride + block]); ne_pack = 16: no norms (thick-restart compression).  X columns need the padded
+// stride of the basis (rows behind n are written as zeros).
+void launch_ritz(hipStream_t s, const double* V, int64_t ldv, int nvec, const double* St_dev, int ne_pack, int nev,
                  double* X, int64_t ldx, int64_t n, double* partials, int pstride, int grid);
 // per column: first local ENTRY with |z| > 0 (n if none) and its value: out[3e] = index, out[3e+1..2] = (re, im);
 // es = doubles per entry, ldx in doubles

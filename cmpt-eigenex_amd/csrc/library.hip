@@ -1512,19 +1512,23 @@ int eigenex_lanczos_restart(eigenex_basis_t b, int nkeep, const double* S, int l
   if (ct.stopped || m < 1 || ct.nalpha != m + 1) return fail(EIGENEX_ERR_STATE, "eigenex_lanczos_restart: no complete Lanczos state to restart from");
   if (nkeep > m || lds < m) return fail(EIGENEX_ERR_ARG, "eigenex_lanczos_restart: nkeep/lds out of range");
   if (b->cap < m + 1 + nkeep) return fail(EIGENEX_ERR_STATE, "eigenex_lanczos_restart: capacity must be >= nvec + nkeep (scratch columns)");
-  const int E = 8;
+  // all coefficient blocks at once: block c holds Ritz vectors [16c, 16c+16), packed [m][16], zero-padded
+  const int E = 16;
+  const int nchunk = (nkeep + E - 1) / E;
+  std::vector<double> St((size_t)nchunk * m * E, 0.0);
+  for (int e = 0; e < nkeep; ++e)
+    for (int j = 0; j < m; ++j) St[((size_t)(e / E) * m + j) * E + e % E] = S[(size_t)e * lds + j];
   double* d_S = nullptr;
-  HIPCHK(hipMalloc(&d_S, sizeof(double) * (size_t)m * E));
+  HIPCHK(hipMalloc(&d_S, sizeof(double) * St.size()));
   int rc = [&]() -> int {
-    for (int e0 = 0; e0 < nkeep; e0 += E) {
-      const int ne = std::min(E, nkeep - e0);
-      for (int e = 0; e < ne; ++e)
-        HIPCHK(hipMemcpyAsync(d_S + (size_t)e * m, S + (size_t)(e0 + e) * lds, sizeof(double) * m, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_S, St.data(), sizeof(double) * St.size(), hipMemcpyHostToDevice, c->stream));
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const int e0 = ch * E, ne = std::min(E, nkeep - e0);
       for (auto& s : b->sh) {
         ProfScope ps(c, EIGENEX_K_RITZ, 8.0 * s.nd * m + 8.0 * s.nd * ne);
-        launch_ritz(c->stream, s.V, s.ldd, m, d_S, m, ne, s.V + (size_t)(m + 1 + e0) * s.ldd, s.ldd, s.nd, s.partials, s.pstride, s.g_vec);
+        launch_ritz(c->stream, s.V, s.ldd, m, d_S + (size_t)ch * m * E, E, ne, s.V + (size_t)(m + 1 + e0) * s.ldd, s.ldd, s.nd,
+                    s.partials, s.pstride, s.g_vec);
       }
-      HIPCHK(hipStreamSynchronize(c->stream));  // d_S is reused by the next chunk
     }
     for (auto& s : b->sh) {
       const size_t vb = sizeof(double) * (size_t)s.ldd;
@@ -1586,12 +1590,15 @@ namespace {
 // parts alike).  hbuf[0..ne) receives the all-reduced squared norms of the raw columns.
 int ritz_raw(eigenex_basis_s* b, int nvec, int ne, const double* const* cols, double* d_S) {
   eigenex_context_s* c = b->ctx;
+  std::vector<double> St((size_t)std::max(nvec, 1) * 8, 0.0);  // packed [nvec][8]
   for (int e = 0; e < ne; ++e)
-    HIPCHK(hipMemcpyAsync(d_S + (size_t)e * nvec, cols[e], sizeof(double) * nvec, hipMemcpyHostToDevice, c->stream));
+    for (int j = 0; j < nvec; ++j) St[(size_t)j * 8 + e] = cols[e][j];
+  HIPCHK(hipMemcpyAsync(d_S, St.data(), sizeof(double) * St.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));  // St is a stack-lifetime staging buffer
   for (auto& s : b->sh) {
     {
       ProfScope ps(c, EIGENEX_K_RITZ, 8.0 * s.nd * nvec + 8.0 * s.nd * ne);
-      launch_ritz(c->stream, s.V, s.ldd, nvec, d_S, nvec, ne, s.X, s.ldd, s.nd, s.partials, s.pstride, s.g_vec);
+      launch_ritz(c->stream, s.V, s.ldd, nvec, d_S, 8, ne, s.X, s.ldd, s.nd, s.partials, s.pstride, s.g_vec);
     }
     launch_reduce(c->stream, s.partials, s.pstride, s.g_vec, ne, s.hbuf, s.ctrl_zero);
   }

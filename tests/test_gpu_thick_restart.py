@@ -124,6 +124,17 @@ def test_thick_restart_laplacian_matches_oracle_and_analytic(mods, operator):
         assert X[np.flatnonzero(X[:, e])[0], e] > 0
     assert es.log()[-2] == "INFO      thick-restart lanczos converged with tolerance"
     assert r["operatorApplications"] == ref["matvecs"] or abs(r["restarts"] - ref["restarts"]) == 1
+    # a second compute() reuses the device slab (no re-allocation) and must reproduce the first bit for bit;
+    # a larger basis afterwards re-creates it
+    es.compute()
+    r2 = es.results()
+    np.testing.assert_array_equal(r2["eigenvalues"], r["eigenvalues"])
+    np.testing.assert_array_equal(r2["eigenvectors"], r["eigenvectors"])
+    assert (r2["restarts"], r2["operatorApplications"]) == (r["restarts"], r["operatorApplications"])
+    es.set(maxBasisSize=m + 12).compute()
+    r3 = es.results()
+    assert r3["info_name"] == "Success"
+    np.testing.assert_allclose(r3["eigenvalues"], lam, rtol=0, atol=1e-8)
     if ctx:
         ctx.close()
 
