@@ -72,6 +72,7 @@ SIGNATURES = {
     "eigenex_csr_destroy": (C.c_int, [_vp]),
     "eigenex_csr_upload_ex": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int64, _ip, _ip, _dp, C.c_int, C.c_int, C.POINTER(_vp)]),
     "eigenex_csr_column_blocks": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "eigenex_block_upload": (C.c_int, [_vp, C.c_int64, C.c_int, _lp, C.c_int, _lp, C.c_int64, _lp, _lp, C.POINTER(C.c_void_p), C.POINTER(_vp)]),
     "eigenex_csr_info": (C.c_int, [_vp, _lp, _lp, _lp, _lp]),
     "eigenex_basis_create": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.POINTER(_vp)]),
     "eigenex_basis_create_ex": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
@@ -230,6 +231,50 @@ class Csr:
             _chk(lib().eigenex_csr_upload(ctx.h, n_global, row_begin, rp.size - 1, _i(rp), _i(cl), vp, C.byref(h)))
         obj = cls(ctx, h)
         obj.is_complex = bool(np.iscomplexobj(val))
+        return obj
+
+    @classmethod
+    def upload_blocks(cls, ctx: Context, row_sizes, col_sizes, blocks):
+        """eigenex_block_upload: blocks = {(qr, qc): 2-D float64 array of shape (row_sizes[qr], col_sizes[qc])}."""
+        rs = np.ascontiguousarray(row_sizes, np.int64)
+        cs = np.ascontiguousarray(col_sizes, np.int64)
+        keys = list(blocks.keys())
+        mats = []
+        for (r, c) in keys:
+            m = np.asfortranarray(blocks[(r, c)], np.float64)
+            if not (0 <= r < rs.size and 0 <= c < cs.size) or m.shape != (rs[r], cs[c]):
+                raise ValueError(f"block ({r}, {c}): shape {m.shape} does not match the partition")
+            mats.append(m)
+        qr = np.array([k[0] for k in keys], np.int64)
+        qc = np.array([k[1] for k in keys], np.int64)
+        ptrs = (C.c_void_p * max(len(mats), 1))(*[m.ctypes.data for m in mats])
+        h = _vp()
+        _chk(lib().eigenex_block_upload(ctx.h, int(rs.sum()), rs.size, rs.ctypes.data_as(_lp), cs.size, cs.ctypes.data_as(_lp),
+                                        len(mats), qr.ctypes.data_as(_lp), qc.ctypes.data_as(_lp), ptrs, C.byref(h)))
+        obj = cls(ctx, h)
+        obj.is_complex = False
+        return obj
+
+    @classmethod
+    def upload_blocks_raw(cls, ctx: Context, row_sizes, col_sizes, qr, qc, values, offsets):
+        """eigenex_block_upload for many blocks without a Python object per block: block k is the column-major
+        array starting at values[offsets[k]] (values: one contiguous float64 array)."""
+        rs = np.ascontiguousarray(row_sizes, np.int64)
+        cs = np.ascontiguousarray(col_sizes, np.int64)
+        qr = np.ascontiguousarray(qr, np.int64)
+        qc = np.ascontiguousarray(qc, np.int64)
+        values = np.ascontiguousarray(values, np.float64)
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        sizes = rs[qr] * cs[qc]
+        if qr.size and (offsets.min() < 0 or (offsets + sizes).max() > values.size):
+            raise ValueError("a block reaches outside the value array")
+        ptrs = (values.ctypes.data + 8 * offsets).astype(np.uint64)
+        h = _vp()
+        _chk(lib().eigenex_block_upload(ctx.h, int(rs.sum()), rs.size, rs.ctypes.data_as(_lp), cs.size, cs.ctypes.data_as(_lp),
+                                        qr.size, qr.ctypes.data_as(_lp), qc.ctypes.data_as(_lp),
+                                        C.cast(ptrs.ctypes.data, C.POINTER(C.c_void_p)), C.byref(h)))
+        obj = cls(ctx, h)
+        obj.is_complex = False
         return obj
 
     @classmethod

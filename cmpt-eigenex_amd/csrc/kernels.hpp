@@ -69,6 +69,23 @@ enum { kPassCarry = 1, kPassNotLast = 2 };
 void launch_spmv(hipStream_t s, const int32_t* rowptr, const int32_t* col, const double* val, const double* x_ext,
                  const double* scale, double shift, double* y, double* u_out, int64_t n, double* partials, int grid,
                  const Ctrl* ctrl, int xcd_aware = 1, int pass = 0);
+// Block-sparse operator (the reference's BlockTensor<Scalar,2> layout, block_tensor.hpp:1193-1206, real fp64):
+// 8 bytes per stored entry plus one column index per block COLUMN (4/rows bytes per entry) instead of CSR's 12.
+//   group g = the rows of one sector that this shard owns, rows grow0[g] .. grow0[g+1].  Its blocks, side by side,
+//             are one dense column-major strip rows(g) x W(g) at bval[gent[g]]; the input column of strip column j
+//             is cols[gcol[g] + j] (local/halo numbering); rowgrp[r] = group of row r
+// Summation order: strip columns ascending = block by block, columns ascending = the stored order of the
+// flattened rows, products rounded before they are added -- bit-identical to k_spmv on the CSR form.
+struct BlockOperatorView {
+  const double* bval;
+  const int64_t* gent;
+  const int64_t* gcol;
+  const int32_t* cols;
+  const int32_t* grow0;
+  const int32_t* rowgrp;
+};
+void launch_block_spmv(hipStream_t s, const BlockOperatorView& op, const double* x_ext, const double* scale, double shift,
+                       double* y, double* u_out, int64_t n, double* partials, int grid, const Ctrl* ctrl);
 // host-operator path: u_out = x*scale
 void launch_scale(hipStream_t s, const double* x, const double* scale_dev, double scale_host, double* out, int64_t n,
                   const Ctrl* ctrl);

@@ -159,6 +159,12 @@ struct CsrShard {
   int32_t* rowptr = nullptr;
   int32_t* col = nullptr;
   double* val = nullptr;
+  // block-sparse format (eigenex_block_upload; kernels.hpp: BlockOperatorView) instead of rowptr/col/val
+  bool blocked = false;
+  double* bval = nullptr;
+  int64_t *gent = nullptr, *gcol = nullptr;
+  int32_t *cols = nullptr, *grow0 = nullptr, *rowgrp = nullptr;
+  int64_t nstripcols = 0;  // entries of cols
   std::vector<Segment> recv, send;
   int32_t* send_idx = nullptr;  // device, concatenated local row indices
   double* sendbuf = nullptr;    // device
@@ -287,6 +293,8 @@ void free_csr_shard(CsrShard& s) {
   if (s.val) (void)hipFree(s.val);
   if (s.send_idx) (void)hipFree(s.send_idx);
   if (s.sendbuf) (void)hipFree(s.sendbuf);
+  for (void* p : {(void*)s.bval, (void*)s.gent, (void*)s.gcol, (void*)s.cols, (void*)s.grow0, (void*)s.rowgrp})
+    if (p) (void)hipFree(p);
   s = CsrShard();
 }
 
@@ -463,6 +471,106 @@ int build_shard_host(eigenex_context_s* c, int64_t n_global, int gshard, const i
   HIPCHK(hipMemcpyAsync(s.rowptr, lrp.data(), sizeof(int32_t) * nrp, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(s.col, lcol.data(), sizeof(int32_t) * (s.nnz + 8), hipMemcpyHostToDevice, c->stream));
   if (s.nnz) HIPCHK(hipMemcpyAsync(s.val, vsrc, sizeof(double) * s.nnz * es, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  build_recv(s, n_global, c->P);
+  return 0;
+}
+
+// Host-side shard construction from dense blocks (the reference's BlockTensor<Scalar,2> storage,
+// block_tensor.hpp:1193-1206): sector sizes rs/cs, block k = sector (qr[k], qc[k]), rs[qr] x cs[qc] column-major.
+// `order` lists the blocks sorted by (qr, qc).  A group is the part of a sector that this shard owns (row slices are
+// copied out of the caller's blocks); a block whose columns straddle the shard's own row range is split into
+// halo-below / own / halo-above pieces, in that (global column) order.
+template <class T>
+int upload_vec(eigenex_context_s* c, T** dev, const std::vector<T>& host, size_t extra = 0) {
+  HIPCHK(hipMalloc(dev, sizeof(T) * (host.size() + extra + 1)));
+  HIPCHK(hipMemsetAsync(*dev, 0, sizeof(T) * (host.size() + extra + 1), c->stream));
+  if (!host.empty()) HIPCHK(hipMemcpyAsync(*dev, host.data(), sizeof(T) * host.size(), hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+
+int build_block_shard_host(eigenex_context_s* c, int64_t n_global, int gshard, const std::vector<int64_t>& ro,
+                           const std::vector<int64_t>& co, const std::vector<int>& order, const int64_t* qr,
+                           const int64_t* qc, const double* const* blocks, CsrShard& s) {
+  s.gshard = gshard;
+  s.es = 1;
+  s.blocked = true;
+  partition(n_global, c->P, gshard, &s.rb, &s.re);
+  s.nloc = s.re - s.rb;
+  s.npad = pad_rows(s.nloc);
+  const int64_t nsr = (int64_t)ro.size() - 1;
+  // sector rows that intersect [rb, re), and their blocks in `order`
+  const int64_t q_first = std::upper_bound(ro.begin(), ro.end(), s.rb) - ro.begin() - 1;
+  std::vector<int64_t> first_of((size_t)nsr + 1, (int64_t)order.size());  // first position in `order` of sector row q
+  for (int64_t p = (int64_t)order.size() - 1; p >= 0; --p) first_of[(size_t)qr[order[p]]] = p;
+  for (int64_t q = nsr - 1; q >= 0; --q) first_of[(size_t)q] = std::min(first_of[(size_t)q], first_of[(size_t)q + 1]);
+  auto pieces = [&](int64_t A, int64_t B, int64_t (&pc)[3][2]) {
+    pc[0][0] = A, pc[0][1] = std::min(B, s.rb);
+    pc[1][0] = std::max(A, s.rb), pc[1][1] = std::min(B, s.re);
+    pc[2][0] = std::max(A, s.re), pc[2][1] = B;
+  };
+  // pass 1: remote columns
+  std::vector<int32_t> rem;
+  for (int64_t q = std::max<int64_t>(q_first, 0); q < nsr && ro[(size_t)q] < s.re; ++q) {
+    if (ro[(size_t)q + 1] <= s.rb) continue;
+    for (int64_t p = first_of[(size_t)q]; p < first_of[(size_t)q + 1]; ++p) {
+      const int k = order[(size_t)p];
+      int64_t pc[3][2];
+      pieces(co[(size_t)qc[k]], co[(size_t)qc[k] + 1], pc);
+      for (int h : {0, 2})
+        for (int64_t g = pc[h][0]; g < pc[h][1]; ++g) rem.push_back((int32_t)g);
+    }
+  }
+  std::sort(rem.begin(), rem.end());
+  rem.erase(std::unique(rem.begin(), rem.end()), rem.end());
+  s.halo_cols.swap(rem);
+  s.nhalo = (int64_t)s.halo_cols.size();
+  if (s.npad + s.nhalo > 2147483647) return fail(EIGENEX_ERR_ARG, "local + halo columns exceed int32");
+  // pass 2: groups (dense strips), their column lists, value slab
+  std::vector<double> bval;
+  std::vector<int64_t> gent, gcol;
+  std::vector<int32_t> cols, grow0, rowgrp((size_t)s.nloc);
+  for (int64_t q = std::max<int64_t>(q_first, 0); q < nsr && ro[(size_t)q] < s.re; ++q) {
+    const int64_t R = ro[(size_t)q + 1] - ro[(size_t)q];
+    const int64_t i0 = std::max(s.rb, ro[(size_t)q]) - ro[(size_t)q], i1 = std::min(s.re, ro[(size_t)q + 1]) - ro[(size_t)q];
+    if (i1 > i0) {
+      const int64_t ic = i0, nr = i1 - i0;
+      grow0.push_back((int32_t)(ro[(size_t)q] + ic - s.rb));
+      gent.push_back((int64_t)bval.size());
+      gcol.push_back((int64_t)cols.size());
+      for (int64_t p = first_of[(size_t)q]; p < first_of[(size_t)q + 1]; ++p) {
+        const int k = order[(size_t)p];
+        const int64_t A = co[(size_t)qc[k]];
+        int64_t pc[3][2];
+        pieces(A, co[(size_t)qc[k] + 1], pc);
+        for (int h = 0; h < 3; ++h) {
+          if (pc[h][1] <= pc[h][0]) continue;
+          const int64_t a = pc[h][0];
+          const int64_t c0 = h == 1 ? a - s.rb
+                                    : s.npad + (std::lower_bound(s.halo_cols.begin(), s.halo_cols.end(), (int32_t)a) - s.halo_cols.begin());
+          const double* src = blocks[k];
+          for (int64_t j = a - A; j < pc[h][1] - A; ++j) {
+            cols.push_back((int32_t)(c0 + (j - (a - A))));
+            bval.insert(bval.end(), src + j * R + ic, src + j * R + ic + nr);
+          }
+        }
+      }
+    }
+  }
+  const int64_t ngrp = (int64_t)grow0.size();
+  s.nnz = (int64_t)bval.size();
+  grow0.push_back((int32_t)s.nloc);
+  gent.push_back((int64_t)bval.size());
+  gcol.push_back((int64_t)cols.size());
+  for (int64_t g = 0; g < ngrp; ++g)
+    for (int32_t r = grow0[(size_t)g]; r < grow0[(size_t)g + 1]; ++r) rowgrp[(size_t)r] = (int32_t)g;
+  s.nstripcols = (int64_t)cols.size();
+  CHK(upload_vec(c, &s.bval, bval, 8));
+  CHK(upload_vec(c, &s.gent, gent));
+  CHK(upload_vec(c, &s.gcol, gcol));
+  CHK(upload_vec(c, &s.cols, cols));
+  CHK(upload_vec(c, &s.grow0, grow0));
+  CHK(upload_vec(c, &s.rowgrp, rowgrp));
   HIPCHK(hipStreamSynchronize(c->stream));
   build_recv(s, n_global, c->P);
   return 0;
@@ -647,6 +755,11 @@ int enq_orthogonalize(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_t
 void launch_operator(hipStream_t st, const CsrShard* m, int es, const double* x_ext, const double* scale, double shift,
                      double shift_im, double* y, double* u_out, double* partials, int pstride, int grid, const Ctrl* ctrl,
                      int flags) {
+  if (m->blocked) {
+    const BlockOperatorView op{m->bval, m->gent, m->gcol, m->cols, m->grow0, m->rowgrp};
+    launch_block_spmv(st, op, x_ext, scale, shift, y, u_out, m->nloc, partials, grid, ctrl);
+    return;
+  }
   for (int k = 0; k < m->passes; ++k) {
     const bool last = k == m->passes - 1;
     const int pass = (k > 0 ? kPassCarry : 0) | (last ? 0 : kPassNotLast);
@@ -669,7 +782,8 @@ int enq_apply(eigenex_basis_s* b, int ucol, bool want_dot) {
     for (auto& s : b->sh) {
       CsrShard* m = s.csr;
       {
-        ProfScope ps(c, EIGENEX_K_SPMV, (4.0 + 8.0 * b->es) * m->nnz + 4.0 * (m->nloc + 1) + 32.0 * s.nd + (want_dot ? 16.0 * s.nd : 0.0));
+        const double opbytes = m->blocked ? 8.0 * m->nnz + 4.0 * m->nstripcols + 4.0 * m->nloc : (4.0 + 8.0 * b->es) * m->nnz + 4.0 * (m->nloc + 1);
+        ProfScope ps(c, EIGENEX_K_SPMV, opbytes + 32.0 * s.nd + (want_dot ? 16.0 * s.nd : 0.0));
         launch_operator(c->stream, m, b->es, s.w, &s.ctrl->scale, b->shift, b->shift_im, s.v, s.V + (int64_t)ucol * s.ldd,
                         want_dot ? s.partials : nullptr, s.pstride, s.g_spmv, s.ctrl, s.xcd_aware);
       }
@@ -1042,6 +1156,52 @@ int eigenex_csr_upload(eigenex_context_t c, int64_t n_global, int64_t row_begin,
 int eigenex_csr_upload_ex(eigenex_context_t c, int64_t n_global, int64_t row_begin, int64_t n_rows, const int32_t* rowptr,
                           const int32_t* col_global, const double* val, int is_complex, int column_blocks, eigenex_csr_t* out) {
   return csr_upload_impl(c, n_global, row_begin, n_rows, rowptr, col_global, val, is_complex ? 2 : 1, column_blocks, out);
+}
+
+int eigenex_block_upload(eigenex_context_t c, int64_t n_global, int n_row_sectors, const int64_t* row_sizes, int n_col_sectors,
+                         const int64_t* col_sizes, int64_t nblocks, const int64_t* qr, const int64_t* qc,
+                         const double* const* blocks, eigenex_csr_t* out) {
+  if (!c || !out || !row_sizes || !col_sizes || n_global <= 0 || n_row_sectors < 1 || n_col_sectors < 1 || nblocks < 0 ||
+      (nblocks > 0 && (!qr || !qc || !blocks)) || nblocks > 2147483000)
+    return fail(EIGENEX_ERR_ARG, "eigenex_block_upload: bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  std::vector<int64_t> ro((size_t)n_row_sectors + 1, 0), co((size_t)n_col_sectors + 1, 0);
+  for (int q = 0; q < n_row_sectors; ++q) {
+    if (row_sizes[q] < 0) return fail(EIGENEX_ERR_ARG, "negative sector size");
+    ro[(size_t)q + 1] = ro[(size_t)q] + row_sizes[q];
+  }
+  for (int q = 0; q < n_col_sectors; ++q) {
+    if (col_sizes[q] < 0) return fail(EIGENEX_ERR_ARG, "negative sector size");
+    co[(size_t)q + 1] = co[(size_t)q] + col_sizes[q];
+  }
+  if (ro.back() != n_global || co.back() != n_global) return fail(EIGENEX_ERR_ARG, "sector sizes must add up to n_global on both axes");
+  std::vector<int> order((size_t)nblocks);
+  for (int64_t k = 0; k < nblocks; ++k) {
+    if (qr[k] < 0 || qr[k] >= n_row_sectors || qc[k] < 0 || qc[k] >= n_col_sectors) return fail(EIGENEX_ERR_ARG, "block index out of range");
+    if (!blocks[k] && row_sizes[qr[k]] * col_sizes[qc[k]] > 0) return fail(EIGENEX_ERR_ARG, "block pointer is NULL");
+    order[(size_t)k] = (int)k;
+  }
+  std::sort(order.begin(), order.end(), [&](int a, int b) { return qr[a] != qr[b] ? qr[a] < qr[b] : qc[a] < qc[b]; });
+  for (int64_t p = 1; p < nblocks; ++p)
+    if (qr[order[(size_t)p]] == qr[order[(size_t)p - 1]] && qc[order[(size_t)p]] == qc[order[(size_t)p - 1]])
+      return fail(EIGENEX_ERR_ARG, "duplicate block index (add the blocks before uploading)");
+  auto* m = new eigenex_csr_s();
+  m->ctx = c;
+  m->n_global = n_global;
+  m->es = 1;
+  m->sh.resize(c->local.size());
+  int rc = 0;
+  for (size_t i = 0; i < c->local.size() && !rc; ++i)
+    rc = build_block_shard_host(c, n_global, c->local[i], ro, co, order, qr, qc, blocks, m->sh[i]);
+  if (!rc && c->P > 1) rc = c->loopback ? build_send_lists_loopback(c, m) : exchange_send_lists_rccl(c, n_global, m->sh[0]);
+  if (rc) {
+    std::string keep = g_err;
+    eigenex_csr_destroy(m);
+    g_err = keep;
+    return rc;
+  }
+  *out = m;
+  return 0;
 }
 
 int eigenex_csr_column_blocks(eigenex_csr_t m, int* passes) {

@@ -6,11 +6,11 @@
 // of the column blocks: y[off_r[q_r] + i] += sum_j B_{q_r,q_c}(i, j) * x[off_c[q_c] + j], visiting the
 // stored blocks in map order (lexicographic {q_r, q_c}) (block_tensor.hpp:2015-2055).  Missing blocks are zero.
 //
-// BlockSparseMatrix is the same description without Eigen; device::csrFromBlocks turns it into the
-// device-resident CSR operator of this library (row entries ordered by block column, then by column inside
-// the block, i.e. ascending columns), so sharding, halo exchange and the SpMV kernel are shared.  A native
-// block kernel (8 instead of 12 bytes per stored entry) is a possible refinement; with m = 128 basis
-// vectors the orthogonalisation moves ~20x more bytes than the operator either way.
+// BlockSparseMatrix is the same description without Eigen.  Two ways onto the device:
+//   device::blockOperator   keeps the blocks dense (eigenex_block_upload: 8 bytes per stored entry + one column
+//                           index per block column; its own kernel; real fp64) -- the default choice
+//   device::csrFromBlocks   flattens to the CSR operator (12 bytes per entry; real or complex)
+// Both add a row's products block by block, columns ascending, and give bit-identical results.
 #pragma once
 
 #include <array>
@@ -99,6 +99,23 @@ class BlockSparseMatrix {
 };
 
 namespace device {
+
+inline std::shared_ptr<CsrOperator> blockOperator(std::shared_ptr<Context> ctx, const BlockSparseMatrix<double>& H) {
+  if (H.rows() != H.cols()) throw LanczosException("a Krylov operator must be square");
+  std::vector<std::int64_t> rs(H.rowSizes().begin(), H.rowSizes().end()), cs(H.colSizes().begin(), H.colSizes().end());
+  std::vector<std::int64_t> qr, qc;
+  std::vector<const double*> ptr;
+  for (const auto& kv : H.blocks()) {
+    qr.push_back(kv.first[0]);
+    qc.push_back(kv.first[1]);
+    ptr.push_back(kv.second.data());
+  }
+  eigenex_csr_t h = nullptr;
+  check(eigenex_block_upload(ctx->handle(), H.rows(), static_cast<int>(rs.size()), rs.data(), static_cast<int>(cs.size()), cs.data(),
+                             static_cast<std::int64_t>(ptr.size()), qr.data(), qc.data(), ptr.data(), &h),
+        "eigenex_block_upload");
+  return CsrOperator::adopt(std::move(ctx), h);
+}
 
 inline std::shared_ptr<CsrOperator> csrFromBlocks(std::shared_ptr<Context> ctx, const BlockSparseMatrix<double>& H) {
   if (H.rows() != H.cols()) throw LanczosException("a Krylov operator must be square");

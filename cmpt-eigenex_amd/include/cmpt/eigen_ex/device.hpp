@@ -108,6 +108,12 @@ class CsrOperator {
     check(eigenex_csr_info(h, &op->n_, nullptr, nullptr, nullptr), "eigenex_csr_info");
     return op;
   }
+  // takes ownership of a handle made by one of the C entry points (eigenex_block_upload, eigenex_csr_upload_ex, ...)
+  static std::shared_ptr<CsrOperator> adopt(std::shared_ptr<Context> ctx, eigenex_csr_t h) {
+    std::shared_ptr<CsrOperator> op = borrow(std::move(ctx), h);
+    op->owned_ = true;
+    return op;
+  }
   ~CsrOperator() {
     if (owned_ && h_) eigenex_csr_destroy(h_);
   }

@@ -1,7 +1,9 @@
 """BASELINE config 5 on one MI355X: block-sparse symmetric "Hamiltonian" (BlockTensor<double,2> layout: uniform
 sectors of size b, stored blocks (q,q) and (q,q+-1)), N ~ 5e7, thick-restart Lanczos m = 128.
 The blocks are generated already flattened (what device::csrFromBlocks produces), in row chunks.
-usage: python scripts/run_config5.py [N=50000000] [b=10] [nev=4] [max_restarts=6] [--json out.json]
+usage: python scripts/run_config5.py [N=50000000] [b=10] [nev=4] [max_restarts=6] [--json out.json] [--csr]
+Default operator format: dense blocks on the device (eigenex_block_upload, 8 B per stored entry); --csr: the same
+matrix flattened to CSR (12 B per entry).
 Prints operator applications per second and checks size-independent properties: every returned Ritz pair's true
 residual ||H x - theta x|| equals the solver's own estimate, Ritz vectors orthonormal."""
 import json, sys, time
@@ -57,8 +59,26 @@ print(f"generated N={N} sectors={nq} (b={b}) nnz={nnz} in {t_gen:.1f} s", flush=
 
 ctx = capi.Context()
 t0 = time.perf_counter()
-A = capi.Csr.upload(ctx, N, rowptr.astype(np.int32), col, val)
-print(f"uploaded in {time.perf_counter()-t0:.1f} s, column blocks {A.column_blocks()}", flush=True)
+use_csr = "--csr" in sys.argv
+if use_csr:
+    A = capi.Csr.upload(ctx, N, rowptr.astype(np.int32), col, val)
+else:
+    # the same entries as dense b x b blocks (q, q-1), (q, q), (q, q+1), column-major each: a row of the flattened
+    # matrix holds its blocks' rows side by side, so block (q, c) = val[rows of q, b columns] transposed
+    first, last = val[: b * 2 * b].reshape(b, 2, b), val[nnz - b * 2 * b:].reshape(b, 2, b)
+    mid = val[b * 2 * b: nnz - b * 2 * b].reshape(nq - 2, b, 3, b)  # [sector, row, block, column]
+    bl_mid = np.ascontiguousarray(mid.transpose(0, 2, 3, 1))          # [sector, block, column, row] = column-major blocks
+    bl_first = np.ascontiguousarray(first.transpose(1, 2, 0))
+    bl_last = np.ascontiguousarray(last.transpose(1, 2, 0))
+    values = np.concatenate([bl_first.ravel(), bl_mid.ravel(), bl_last.ravel()])
+    del mid, bl_mid
+    q_mid = np.repeat(np.arange(1, nq - 1, dtype=np.int64), 3)
+    qr_ = np.concatenate([[0, 0], q_mid, [nq - 1, nq - 1]])
+    qc_ = np.concatenate([[0, 1], q_mid + np.tile(np.array([-1, 0, 1], np.int64), nq - 2), [nq - 2, nq - 1]])
+    offsets = np.arange(qr_.size, dtype=np.int64) * (b * b)
+    sizes = np.full(nq, b, np.int64)
+    A = capi.Csr.upload_blocks_raw(ctx, sizes, sizes, qr_, qc_, values, offsets)
+print(f"uploaded ({'CSR' if use_csr else 'dense blocks'}) in {time.perf_counter()-t0:.1f} s, stored entries {A.info()['nnz_local']}", flush=True)
 init = np.random.default_rng(5).standard_normal(N)
 es = solver.ThickRestartLanczosEigenSolver()
 es.setDeviceOperator(A).set(numberOfEigenvalues=nev, maxBasisSize=128, tolerance=1e-10, maxRestarts=max_restarts, initialVector=init)
@@ -100,7 +120,7 @@ G = X.T @ X
 print("max |X^T X - I| =", np.abs(G - np.eye(G.shape[0])).max())
 assert np.abs(G - np.eye(G.shape[0])).max() < 1e-9
 if out_json:
-    json.dump(dict(N=N, sector=b, nnz=nnz, m=128, nev=nev, restarts=r["restarts"], info=r["info_name"], operator_applications=napp,
+    json.dump(dict(format="csr" if use_csr else "blocks", N=N, sector=b, nnz=nnz, m=128, nev=nev, restarts=r["restarts"], info=r["info_name"], operator_applications=napp,
                    seconds=dt, it_per_s=napp / dt, eigenvalues=list(map(float, r["eigenvalues"])),
                    residuals=list(map(float, r["residuals"])), kernels=prof), open(out_json, "w"), indent=1)
 print("OK")
