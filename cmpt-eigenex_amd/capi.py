@@ -89,6 +89,7 @@ SIGNATURES = {
     "eigenex_basis_capacity": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "eigenex_basis_tune": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),
     "eigenex_ritz_vectors_complex": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, C.c_int, _dp, C.c_int64]),
+    "eigenex_krylov_combine": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, C.c_int, _dp, C.c_int64]),
     "eigenex_apply": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, _dp]),
     "eigenex_dots": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
     "eigenex_update": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp]),

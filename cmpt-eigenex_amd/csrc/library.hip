@@ -1571,10 +1571,30 @@ static bool cols_ok(eigenex_basis_t b, int first, int stride, int count, int nq)
 }
 
 int eigenex_apply(eigenex_basis_t b, int x_ref, int y_ref, double shift, double* dot) {
-  if (!b || !b->csr) return fail(EIGENEX_ERR_ARG, "eigenex_apply needs a basis with a device CSR operator");
+  if (!b || (!b->csr && !b->fn)) return fail(EIGENEX_ERR_ARG, "eigenex_apply needs a basis with a device operator or a host callback");
   if (y_ref == EIGENEX_VEC_W) return fail(EIGENEX_ERR_ARG, "y may not be the operator input vector");
   eigenex_context_s* c = b->ctx;
   HIPCHK(hipSetDevice(c->device));
+  if (!b->csr) {  // operator in host code (MatMulFunction, lanczos.hpp:116): stage through pinned memory
+    BasisShard& s = b->sh[0];
+    double* x = vec_ptr(s, b->cap, b->nq, x_ref);
+    double* y = vec_ptr(s, b->cap, b->nq, y_ref);
+    if (!x || !y || x == y) return fail(EIGENEX_ERR_ARG, "bad vector reference");
+    HIPCHK(hipMemcpyAsync(b->pin_in, x, sizeof(double) * s.nd, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    b->fn(b->pin_in, b->pin_out, b->fn_user);
+    HIPCHK(hipMemcpyAsync(y, b->pin_out, sizeof(double) * s.nd, hipMemcpyHostToDevice, c->stream));
+    if (dot || shift != 0.0) {
+      if (b->es == 2)
+        launch_shift_dot_z(c->stream, y, x, shift, 0.0, s.nloc, s.partials, s.pstride, s.g_vec, s.ctrl_zero);
+      else
+        launch_shift_dot(c->stream, y, x, shift, s.nloc, s.partials, s.g_vec, s.ctrl_zero);
+      launch_reduce(c->stream, s.partials, s.pstride, s.g_vec, b->es, s.hbuf + b->slot_alpha(), s.ctrl_zero);
+      if (dot) return fetch_h(b, b->slot_alpha(), b->es, dot);
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+  }
   for (auto& s : b->sh) {
     double* x = vec_ptr(s, b->cap, b->nq, x_ref);
     double* y = vec_ptr(s, b->cap, b->nq, y_ref);
@@ -1769,10 +1789,21 @@ int ritz_raw(eigenex_basis_s* b, int nvec, int ne, const double* const* cols, do
 // each column is divided by its norm (nrm2[e], all-reduced) and by the phase z/|z| of its first
 // entry with |z| > 0 in global row order (lanczos.hpp:806-816, arnoldi.hpp:854-865), then copied
 // to the host (rows owned by this context; host column stride ldx entries).
+// raw: copy the combinations out as they are (eigenex_krylov_combine) instead of normalising and fixing the phase
 int ritz_finish(eigenex_basis_s* b, const std::vector<double*>& bufs, const std::vector<int64_t>& ld_doubles, int oes,
-                int ncol, const double* nrm2, double* X, int64_t ldx, int col0) {
+                int ncol, const double* nrm2, double* X, int64_t ldx, int col0, bool raw) {
   eigenex_context_s* c = b->ctx;
   const int E = 8;
+  if (raw) {
+    for (size_t i = 0; i < b->sh.size(); ++i) {
+      BasisShard& s = b->sh[i];
+      for (int e = 0; e < ncol; ++e)
+        HIPCHK(hipMemcpyAsync(X + ((size_t)(col0 + e) * ldx + (s.rb - b->sh[0].rb)) * oes, bufs[i] + (size_t)e * ld_doubles[i],
+                              sizeof(double) * s.nloc * oes, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+  }
   for (size_t i = 0; i < b->sh.size(); ++i)
     launch_first_nonzero(c->stream, bufs[i], ld_doubles[i], ncol, b->sh[i].nloc, oes, b->sh[i].hbuf + E);
   std::vector<double> first((size_t)3 * E * c->P, 0.0);
@@ -1819,12 +1850,8 @@ int ritz_finish(eigenex_basis_s* b, const std::vector<double*>& bufs, const std:
   return 0;
 }
 
-}  // namespace
-
-extern "C" {
-
 // real coefficients (lanczos.hpp:798-816).  X has the basis' scalar type: real, or interleaved complex.
-int eigenex_ritz_vectors(eigenex_basis_t b, int nvec, int nev, const double* S, int lds, double* X, int64_t ldx) {
+int ritz_vectors_real(eigenex_basis_t b, int nvec, int nev, const double* S, int lds, double* X, int64_t ldx, bool raw) {
   if (!b || nvec < 0 || nvec > b->cap || nev < 0 || (nev && (!S || !X)) || lds < nvec) return fail(EIGENEX_ERR_ARG, "eigenex_ritz_vectors: bad argument");
   eigenex_context_s* c = b->ctx;
   HIPCHK(hipSetDevice(c->device));
@@ -1850,7 +1877,7 @@ int eigenex_ritz_vectors(eigenex_basis_t b, int nvec, int nev, const double* S, 
       double nrm2[E];
       HIPCHK(hipMemcpyAsync(nrm2, b->sh[0].hbuf, sizeof(double) * ne, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));
-      CHK(ritz_finish(b, bufs, lds_, b->es, ne, nrm2, X, ldx, e0));
+      CHK(ritz_finish(b, bufs, lds_, b->es, ne, nrm2, X, ldx, e0, raw));
     }
     return 0;
   }();
@@ -1860,8 +1887,8 @@ int eigenex_ritz_vectors(eigenex_basis_t b, int nvec, int nev, const double* S, 
 
 // complex coefficients (arnoldi.hpp:841-865): 4 complex columns per pass over the basis; the basis may be
 // real (real operator, complex Ritz pairs) or complex.  X: interleaved (re, im), column stride ldx entries.
-int eigenex_ritz_vectors_complex(eigenex_basis_t b, int nvec, int nev, const double* S_re, const double* S_im, int lds,
-                                 double* X, int64_t ldx) {
+int ritz_vectors_cplx(eigenex_basis_t b, int nvec, int nev, const double* S_re, const double* S_im, int lds, double* X,
+                      int64_t ldx, bool raw) {
   if (!b || nvec < 0 || nvec > b->cap || nev < 0 || (nev && (!S_re || !S_im || !X)) || lds < nvec) return fail(EIGENEX_ERR_ARG, "eigenex_ritz_vectors_complex: bad argument");
   eigenex_context_s* c = b->ctx;
   HIPCHK(hipSetDevice(c->device));
@@ -1898,7 +1925,7 @@ int eigenex_ritz_vectors_complex(eigenex_basis_t b, int nvec, int nev, const dou
       double nrm2[E];
       HIPCHK(hipMemcpyAsync(nrm2, b->sh[0].hbuf, sizeof(double) * nc, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));
-      CHK(ritz_finish(b, outbuf, ldo, 2, nc, nrm2, X, ldx, e0));
+      CHK(ritz_finish(b, outbuf, ldo, 2, nc, nrm2, X, ldx, e0, raw));
     }
     return 0;
   }();
@@ -1906,6 +1933,24 @@ int eigenex_ritz_vectors_complex(eigenex_basis_t b, int nvec, int nev, const dou
     if (p) (void)hipFree(p);
   (void)hipFree(d_S);
   return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int eigenex_ritz_vectors(eigenex_basis_t b, int nvec, int nev, const double* S, int lds, double* X, int64_t ldx) {
+  return ritz_vectors_real(b, nvec, nev, S, lds, X, ldx, false);
+}
+
+int eigenex_ritz_vectors_complex(eigenex_basis_t b, int nvec, int nev, const double* S_re, const double* S_im, int lds,
+                                 double* X, int64_t ldx) {
+  return ritz_vectors_cplx(b, nvec, nev, S_re, S_im, lds, X, ldx, false);
+}
+
+int eigenex_krylov_combine(eigenex_basis_t b, int nvec, int ncols, const double* C_re, const double* C_im, int ldc, double* X,
+                           int64_t ldx) {
+  return C_im ? ritz_vectors_cplx(b, nvec, ncols, C_re, C_im, ldc, X, ldx, true) : ritz_vectors_real(b, nvec, ncols, C_re, ldc, X, ldx, true);
 }
 
 }  // extern "C"

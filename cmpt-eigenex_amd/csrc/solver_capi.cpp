@@ -19,6 +19,7 @@
 #include "cmpt/eigen_ex/arnoldi.hpp"
 #include "cmpt/eigen_ex/block_operator.hpp"
 #include "cmpt/eigen_ex/lanczos.hpp"
+#include "cmpt/eigen_ex/lanczos_function.hpp"
 #include "cmpt/eigen_ex/thick_restart_lanczos.hpp"
 #include "cmpt/eigen_ex/triplets_operator.hpp"
 
@@ -266,6 +267,78 @@ int tr_get(void* p, double* eigenvalues, double* residuals, double* eigenvectors
   });
 }
 
+// ---- f(H)v / exp(xH)v (lanczos_function.hpp) -----------------------------------------------------
+// kind 0: f(t) = exp(a t); 1: f(t) = 1/(t - a); 2: f(t) = t*t + a
+template <class S>
+std::function<S(S)> make_function(int kind, double a_re, double a_im) {
+  S a;
+  assign_shift(a, a_re, a_im);
+  if (kind == 0) return [a](S t) { return std::exp(a * t); };
+  if (kind == 1) return [a](S t) { return S(1.0) / (t - a); };
+  if (kind == 2) return [a](S t) { return t * t + a; };
+  throw LanczosException("unknown function kind");
+}
+template <class S>
+int lz_exp_with_lanczos(void* p, double x_re, double x_im, double* out) {
+  return guard([&] {
+    auto& es = static_cast<Box<LanczosEigenSolver<S>>*>(p)->es;
+    S x;
+    assign_shift(x, x_re, x_im);
+    DenseVector<S> o;
+    LanczosExponentialSolver<S>::solveWithLanczos(x, es, o);
+    std::memcpy(out, o.data(), sizeof(S) * (size_t)o.size());
+  });
+}
+template <class S>
+int lz_function_of(void* p, int kind, double a_re, double a_im, double* out) {
+  return guard([&] {
+    auto& es = static_cast<Box<LanczosEigenSolver<S>>*>(p)->es;
+    const DenseVector<S> o = LanczosFunctionSolver<S>::solve(make_function<S>(kind, a_re, a_im), es);
+    std::memcpy(out, o.data(), sizeof(S) * (size_t)o.size());
+  });
+}
+template <class S>
+int fn_exp_eigens(double x_re, double x_im, int64_t n, int64_t nev, const double* eivals, const double* eivecs, int64_t max_expand,
+                  const double* in, double* out) {
+  return guard([&] {
+    S x;
+    assign_shift(x, x_re, x_im);
+    DenseVector<double> ev(eivals, (Index)nev);
+    DenseMatrix<S> X((Index)n, (Index)nev);
+    std::memcpy(reinterpret_cast<double*>(X.data()), eivecs, sizeof(S) * (size_t)(n * nev));
+    DenseVector<S> o;
+    LanczosExponentialSolver<S>::solveWithEigens(x, ev, X, (Index)max_expand, make_vector<S>(in, n), o);
+    std::memcpy(out, o.data(), sizeof(S) * (size_t)o.size());
+  });
+}
+template <class S>
+int fn_exp_taylor(eigenex_context_t ctx, eigenex_csr_t csr, eigenex_matvec_fn fn, void* user, int64_t height, double x_re, double x_im,
+                  double radius, const double* in, int64_t n_in, double* out, double error, int64_t max_expansion, int auto_division) {
+  return guard([&] {
+    S x;
+    assign_shift(x, x_re, x_im);
+    auto c = device::Context::borrow(ctx);
+    DenseVector<S> o;
+    const DenseVector<S> v = make_vector<S>(in, n_in);
+    if (csr) {
+      auto op = device::CsrOperator::borrow(c, csr);
+      if (auto_division)
+        LanczosExponentialSolver<S>::solveWithTaylorAutoDivision(x, op, radius, v, o, error, (Index)max_expansion);
+      else
+        LanczosExponentialSolver<S>::solveWithTaylorNoDivision(x, op, radius, v, o, error, (Index)max_expansion);
+    } else {
+      typename LanczosExponentialSolver<S>::MatMulFunction mm = [fn, user](const S* a, S* b) {
+        fn(reinterpret_cast<const double*>(a), reinterpret_cast<double*>(b), user);
+      };
+      if (auto_division)
+        LanczosExponentialSolver<S>::solveWithTaylorAutoDivision(x, std::make_pair(mm, (Index)height), radius, v, o, error, (Index)max_expansion);
+      else
+        LanczosExponentialSolver<S>::solveWithTaylorNoDivision(x, mm, (Index)height, radius, v, o, error, (Index)max_expansion, c);
+    }
+    std::memcpy(out, o.data(), sizeof(S) * (size_t)o.size());
+  });
+}
+
 }  // namespace
 
 extern "C" {
@@ -414,7 +487,9 @@ int eigenex_solver_hessenberg_eigen(int n, const double* H_interleaved, double* 
   int PFX##sizes(void* p, int64_t* out) { return lz_sizes<S>(p, out); }                                                 \
   int PFX##get(void* p, double* a, double* b, double* ev, double* X) { return lz_get<S>(p, a, b, ev, X); }              \
   int PFX##lanczosvector(void* p, int64_t k, double* out) { return lz_vector<S>(p, k, out); }                           \
-  int64_t PFX##convergence_log(void* p, int64_t i, double* out, int64_t cap) { return lz_convergence_log<S>(p, i, out, cap); }
+  int64_t PFX##convergence_log(void* p, int64_t i, double* out, int64_t cap) { return lz_convergence_log<S>(p, i, out, cap); } \
+  int PFX##exp_with_lanczos(void* p, double x_re, double x_im, double* out) { return lz_exp_with_lanczos<S>(p, x_re, x_im, out); } \
+  int PFX##function_of(void* p, int kind, double a_re, double a_im, double* out) { return lz_function_of<S>(p, kind, a_re, a_im, out); }
 
 #define EIGENEX_ARNOLDI_FAMILY(PFX, S)                                                                                  \
   EIGENEX_SOLVER_COMMON(PFX, ArnoldiEigenSolver<S>)                                                                     \
@@ -446,6 +521,19 @@ int eigenex_solver_hessenberg_eigen(int n, const double* H_interleaved, double* 
   int PFX##sizes(void* p, int64_t* out) { return tr_sizes<S>(p, out); }                                                 \
   int PFX##get(void* p, double* ev, double* res, double* X) { return tr_get<S>(p, ev, res, X); }                        \
   const char* PFX##log_line(void* p, int64_t i) { return sv_log_line<ThickRestartLanczosEigenSolver<S>>(p, i); }
+
+int eigenex_solver_exp_eigens(int is_complex, double x_re, double x_im, int64_t n, int64_t nev, const double* eivals,
+                              const double* eivecs, int64_t max_expand, const double* in, double* out) {
+  return is_complex ? fn_exp_eigens<std::complex<double>>(x_re, x_im, n, nev, eivals, eivecs, max_expand, in, out)
+                    : fn_exp_eigens<double>(x_re, x_im, n, nev, eivals, eivecs, max_expand, in, out);
+}
+// operator: csr handle, or (csr == NULL) the host callback fn/user of `height` rows
+int eigenex_solver_exp_taylor(int is_complex, eigenex_context_t ctx, eigenex_csr_t csr, eigenex_matvec_fn fn, void* user, int64_t height,
+                              double x_re, double x_im, double radius, const double* in, int64_t n_in, double* out, double error,
+                              int64_t max_expansion, int auto_division) {
+  return is_complex ? fn_exp_taylor<std::complex<double>>(ctx, csr, fn, user, height, x_re, x_im, radius, in, n_in, out, error, max_expansion, auto_division)
+                    : fn_exp_taylor<double>(ctx, csr, fn, user, height, x_re, x_im, radius, in, n_in, out, error, max_expansion, auto_division);
+}
 
 EIGENEX_TRLANCZOS_FAMILY(eigenex_trlanczos_solver_, double)
 EIGENEX_TRLANCZOS_FAMILY(eigenex_ztrlanczos_solver_, std::complex<double>)

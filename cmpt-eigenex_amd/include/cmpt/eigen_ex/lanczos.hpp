@@ -62,6 +62,13 @@ template <class R>
 struct IsComplex<std::complex<R>> : std::true_type {};
 
 template <class S>
+inline S makeScalar(double re, double im);
+template <>
+inline double makeScalar<double>(double re, double) { return re; }
+template <>
+inline std::complex<double> makeScalar<std::complex<double>>(double re, double im) { return std::complex<double>(re, im); }
+
+template <class S>
 struct SupportedScalar : std::integral_constant<bool, std::is_same<S, double>::value || std::is_same<S, std::complex<double>>::value> {};
 
 // one draw per entry for real scalars; real part then imaginary part for complex ones
@@ -381,7 +388,36 @@ class LanczosBase {
     return X;
   }
 
+  // Extension: sum_m c[m] * (Lanczos vector m), m < count <= alpha().size(), formed in ONE pass over the device
+  // slab (eigenex_krylov_combine) -- any vector of the Krylov space from its coefficients, without materialising
+  // Ritz vectors.  Returns the rows this process owns.
+  VectorType krylovCombination(const Scalar* c, Index count) const {
+    if (count < 0 || count > nvec_ || (count > 0 && !dev_.alive())) throw LanczosException("krylovCombination: no such Lanczos vectors");
+    VectorType out(dev_.alive() ? dev_.localRows() : matrixHeight_);
+    if (count == 0) return out;
+    combine_(c, count, out, std::integral_constant<bool, detail::IsComplex<Scalar>::value>());
+    return out;
+  }
+  // u_0^H * initialVector, computed on the device (= ||initialVector|| when nothing is deflated)
+  Scalar startVectorOverlap() const {
+    if (!dev_.alive() || nvec_ < 1) throw LanczosException("startVectorOverlap: no Lanczos vectors");
+    double h[2] = {0.0, 0.0};
+    device::check(eigenex_dots(dev_.handle(), EIGENEX_VEC_START, 0, 1, 1, 0, h), "eigenex_dots");
+    return detail::makeScalar<Scalar>(h[0], h[1]);
+  }
+
  protected:
+  void combine_(const Scalar* c, Index count, VectorType& out, std::false_type) const {
+    device::check(eigenex_krylov_combine(dev_.handle(), static_cast<int>(count), 1, c, nullptr, static_cast<int>(count), out.data(), out.size()),
+                  "eigenex_krylov_combine");
+  }
+  void combine_(const Scalar* c, Index count, VectorType& out, std::true_type) const {
+    std::vector<double> re(static_cast<std::size_t>(count)), im(static_cast<std::size_t>(count));
+    for (Index m = 0; m < count; ++m) re[static_cast<std::size_t>(m)] = std::real(c[m]), im[static_cast<std::size_t>(m)] = std::imag(c[m]);
+    device::check(eigenex_krylov_combine(dev_.handle(), static_cast<int>(count), 1, re.data(), im.data(), static_cast<int>(count),
+                                         reinterpret_cast<double*>(out.data()), out.size()),
+                  "eigenex_krylov_combine");
+  }
   std::shared_ptr<device::Context> contextOrDefault_() {
     if (!context_) context_ = device::defaultContext();
     return context_;

@@ -79,6 +79,11 @@ def lib():
             getattr(L, p + "lanczosvector").argtypes = [_vp, C.c_int64, _dp]
             getattr(L, p + "convergence_log").argtypes = [_vp, C.c_int64, _dp, C.c_int64]
             getattr(L, p + "convergence_log").restype = C.c_int64
+            getattr(L, p + "exp_with_lanczos").argtypes = [_vp, C.c_double, C.c_double, _dp]
+            getattr(L, p + "function_of").argtypes = [_vp, C.c_int, C.c_double, C.c_double, _dp]
+        L.eigenex_solver_exp_eigens.argtypes = [C.c_int, C.c_double, C.c_double, C.c_int64, C.c_int64, _dp, _dp, C.c_int64, _dp, _dp]
+        L.eigenex_solver_exp_taylor.argtypes = [C.c_int, _vp, _vp, capi.MATVEC_FN, _vp, C.c_int64, C.c_double, C.c_double, C.c_double,
+                                                _dp, C.c_int64, _dp, C.c_double, C.c_int64, C.c_int]
         for kind in ("arnoldi", "zarnoldi"):
             getattr(L, f"eigenex_{kind}_solver_get").argtypes = [_vp, _dp, _dp, _dp, _dp]
         _LIB = L
@@ -180,6 +185,49 @@ def blocks_to_csr(row_sizes, col_sizes, blocks):
                                             qr.ctypes.data_as(_lp), qc.ctypes.data_as(_lp), _d(vals), rowptr.ctypes.data_as(i32),
                                             col.ctypes.data_as(i32), _d(val), C.byref(nnz)))
     return rowptr, col[: nnz.value].copy(), val[: nnz.value].copy()
+
+
+def exp_with_eigens(x, eivals, eivecs, max_expand, vin):
+    """LanczosExponentialSolver::solveWithEigens on explicit host eigenpairs (vector arithmetic on the GPU)."""
+    X = np.asfortranarray(eivecs)
+    cplx = np.iscomplexobj(X) or np.iscomplexobj(vin) or complex(x).imag != 0.0
+    dt = np.complex128 if cplx else np.float64
+    X = np.asfortranarray(X, dt)
+    v = np.ascontiguousarray(vin, dt)
+    ev = np.ascontiguousarray(eivals, np.float64)
+    out = np.zeros(v.size, dt)
+    z = complex(x)
+    _chk(lib().eigenex_solver_exp_eigens(int(cplx), z.real, z.imag, X.shape[0], X.shape[1], _d(ev), _d(X), int(max_expand), _d(v), _d(out)))
+    return out
+
+
+def exp_taylor(x, operator, radius, vin, ctx=None, height=None, error=1.0e-14, max_expansion=-1, auto_division=False, dtype=None):
+    """LanczosExponentialSolver::solveWithTaylor{No,Auto}Division.  operator: a capi.Csr (device) or a callable
+    x -> A x of `height` rows (host callback); vin / result: the rows this process owns."""
+    dt = np.dtype(dtype if dtype is not None else (np.complex128 if (np.iscomplexobj(vin) or complex(x).imag != 0.0) else np.float64))
+    cplx = dt.kind == "c"
+    v = np.ascontiguousarray(vin, dt)
+    out = np.zeros(v.size, dt)
+    z = complex(x)
+    keep = None
+    if isinstance(operator, capi.Csr):
+        assert bool(getattr(operator, "is_complex", False)) == cplx, "scalar type of operator and vector differ"
+        c, csr, cb, h = operator.ctx, operator.h, capi.MATVEC_FN(0), 0
+    else:
+        n, es = int(height), (2 if cplx else 1)
+
+        def tramp(pin, pout, _user):
+            a = np.ctypeslib.as_array(pin, shape=(n * es,)).view(dt)
+            b = np.ctypeslib.as_array(pout, shape=(n * es,)).view(dt)
+            b[:] = operator(a)
+
+        cb = keep = capi.MATVEC_FN(tramp)
+        c = ctx if ctx is not None else capi.Context()
+        csr, h = None, n
+    _chk(lib().eigenex_solver_exp_taylor(int(cplx), c.h, csr, cb, None, h, z.real, z.imag, float(radius), _d(v), v.size, _d(out),
+                                         float(error), int(max_expansion), int(bool(auto_division))))
+    del keep
+    return out
 
 
 def gershgorin_range(n, rows, cols, vals):
@@ -291,6 +339,21 @@ class LanczosEigenSolver(_SolverBase):
     def lanczosvector(self, k: int, n_rows: int):
         out = np.empty(n_rows, self.dtype)
         _chk(self._f("lanczosvector")(self.h, k, _d(out)))
+        return out
+
+    def expWithLanczos(self, x, n_rows: int):
+        """LanczosExponentialSolver::solveWithLanczos(x, *this, out): runs compute(), returns exp(xA)|initialVector>
+        (the rows this process owns: n_rows of them)."""
+        out = np.zeros(n_rows, self.dtype)
+        z = complex(x)
+        _chk(self._f("exp_with_lanczos")(self.h, z.real, z.imag, _d(out)))
+        return out
+
+    def functionOf(self, kind: int, a, n_rows: int):
+        """LanczosFunctionSolver::solve(f, *this) on an already computed solver; f by kind: 0 exp(a t), 1 1/(t - a), 2 t^2 + a."""
+        out = np.zeros(n_rows, self.dtype)
+        z = complex(a)
+        _chk(self._f("function_of")(self.h, kind, z.real, z.imag, _d(out)))
         return out
 
     def convergenceLog(self, index: int):

@@ -203,7 +203,8 @@ int eigenex_vec_copy(eigenex_basis_t b, int dst_ref, int src_ref);
 /* ---- step primitives (each one parity-tested on its own; all synchronise) -- */
 /* Complex bases: h / dot arguments hold (re, im) pairs (dots are conjugate-linear in the basis vector,
  * Eigen's a.dot(b) = sum conj(a_i) b_i); host vectors are interleaved.
- * y = A*x + shift*x ; if dot != NULL also *dot = x . y      (a1, a2, a3 of SURVEY 8a) */
+ * y = A*x + shift*x ; if dot != NULL also *dot = x . y      (a1, a2, a3 of SURVEY 8a); works with a CSR/block
+ * handle or, on an unsharded context, with the host callback of eigenex_basis_set_host_operator */
 int eigenex_apply(eigenex_basis_t b, int x_ref, int y_ref, double shift, double* dot);
 /* h[i] = col(first + i*stride) . w, i < count, then h[count + q] = ortho(q) . w, q < n_ortho_used   (a5 dot half) */
 int eigenex_dots(eigenex_basis_t b, int w_ref, int first, int stride, int count, int n_ortho_used, double* h);
@@ -258,6 +259,13 @@ int eigenex_ritz_vectors(eigenex_basis_t b, int nvec, int nev, const double* S, 
  * the phase z/|z| of its first non-zero entry. */
 int eigenex_ritz_vectors_complex(eigenex_basis_t b, int nvec, int nev, const double* S_re, const double* S_im, int lds,
                                  double* X_interleaved, int64_t ldx);
+/* X[:, e] = sum_m C[m + e*ldc] * col(m), m < nvec, e < ncols, returned as it is (no normalisation, no phase):
+ * any vector of the Krylov space from its coefficients in one pass over the basis, e.g. f(A) v ~ V f(T) e_1 |v|
+ * (reference: LanczosFunctionSolver / LanczosExponentialSolver::solveWithEigens, lanczos.hpp:953-1075, which go
+ * through all Ritz vectors instead).  C_im == NULL: real coefficients, X has the basis' scalar type; otherwise
+ * complex coefficients C_re + i C_im and X holds interleaved (re, im) pairs. */
+int eigenex_krylov_combine(eigenex_basis_t b, int nvec, int ncols, const double* C_re, const double* C_im, int ldc,
+                           double* X, int64_t ldx);
 
 #ifdef __cplusplus
 }
