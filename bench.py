@@ -61,8 +61,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=512, help="grid edge (default 512: the BASELINE metric's workload)")
-    ap.add_argument("--m", type=int, default=100, help="Lanczos iterations per solve")
+    # long names: under `python -m torch.distributed.run` short ones like --n / --m are rejected by the launcher's own
+    # parser as ambiguous prefixes of its options (--nnodes, --master-addr, ...)
+    ap.add_argument("--grid-edge", "--n", dest="n", type=int, default=512, help="grid edge (default 512: the BASELINE metric's workload)")
+    ap.add_argument("--krylov-steps", "--m", dest="m", type=int, default=100, help="Lanczos iterations per solve")
     ap.add_argument("--sequential", action="store_true", help="reference-order sequential Gram-Schmidt instead of batched")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
