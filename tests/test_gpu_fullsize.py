@@ -157,3 +157,36 @@ def test_config4_laplacian512_m100_properties(capi):
     a0 = 6.0 * (g3 * g3).sum() - 2.0 * ((g3[1:] * g3[:-1]).sum() + (g3[:, 1:] * g3[:, :-1]).sum() + (g3[:, :, 1:] * g3[:, :, :-1]).sum())
     assert abs(alpha[0] - a0) < 1e-12
     ctx.close()
+
+
+def test_config4_eight_row_shards_match_single_shard(capi):
+    """The headline workload cut into the 8 row shards of the 8-GPU run (64 z-planes each), all on one device
+    through the loopback transport: the device-side Laplacian generator per shard, the closed-form halo plan
+    (one z-plane from each neighbour), local/halo numbering and the reduction points at full size.  alpha/beta
+    must agree with the single-shard run to rounding (the partial sums are grouped per shard)."""
+    n, m = 512, 12
+    N = n ** 3
+    init = np.random.default_rng(20240601).standard_normal(N)
+    res = []
+    for shards in (1, 8):
+        ctx = capi.Context(loopback_shards=shards) if shards > 1 else capi.Context()
+        try:
+            A = capi.Csr.laplacian3d(ctx, n)
+            b = capi.Basis(ctx, A, N, m + 1)
+        except capi.EigenexError as e:  # pragma: no cover
+            pytest.skip(f"not enough device memory for 512^3: {e}")
+        info = A.info()
+        assert info["nnz_local"] == 7 * N - 6 * n * n
+        assert info["n_halo_local"] == (0 if shards == 1 else 14 * n * n)  # 2 planes for 6 inner shards, 1 for the outer two
+        b.upload(capi.VEC_W, init)
+        b.lanczos_enqueue(m + 1)
+        st, alpha, beta = b.lanczos_state()
+        assert (st.nvec, st.iterations, st.stopped) == (m + 1, m, 0)
+        u_last = b.download(capi.VEC_COL(m))
+        res.append((alpha, beta, u_last))
+        b.close()
+        A.close()
+        ctx.close()
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(res[0][1], res[1][1], rtol=0, atol=1e-12)
+    assert np.abs(res[0][2] - res[1][2]).max() < 1e-12
