@@ -73,6 +73,7 @@ SIGNATURES = {
     "eigenex_csr_upload_ex": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int64, _ip, _ip, _dp, C.c_int, C.c_int, C.POINTER(_vp)]),
     "eigenex_csr_column_blocks": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "eigenex_block_upload": (C.c_int, [_vp, C.c_int64, C.c_int, _lp, C.c_int, _lp, C.c_int64, _lp, _lp, C.POINTER(C.c_void_p), C.POINTER(_vp)]),
+    "eigenex_block_upload_z": (C.c_int, [_vp, C.c_int64, C.c_int, _lp, C.c_int, _lp, C.c_int64, _lp, _lp, C.POINTER(C.c_void_p), C.POINTER(_vp)]),
     "eigenex_csr_info": (C.c_int, [_vp, _lp, _lp, _lp, _lp]),
     "eigenex_basis_create": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.POINTER(_vp)]),
     "eigenex_basis_create_ex": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
@@ -236,13 +237,16 @@ class Csr:
 
     @classmethod
     def upload_blocks(cls, ctx: Context, row_sizes, col_sizes, blocks):
-        """eigenex_block_upload: blocks = {(qr, qc): 2-D float64 array of shape (row_sizes[qr], col_sizes[qc])}."""
+        """eigenex_block_upload[_z]: blocks = {(qr, qc): 2-D array of shape (row_sizes[qr], col_sizes[qc])}, all real
+        (float64) or, if any is complex, all uploaded as complex128."""
         rs = np.ascontiguousarray(row_sizes, np.int64)
         cs = np.ascontiguousarray(col_sizes, np.int64)
         keys = list(blocks.keys())
+        cplx = any(np.iscomplexobj(blocks[k]) for k in keys)
+        dt = np.complex128 if cplx else np.float64
         mats = []
         for (r, c) in keys:
-            m = np.asfortranarray(blocks[(r, c)], np.float64)
+            m = np.asfortranarray(blocks[(r, c)], dt)
             if not (0 <= r < rs.size and 0 <= c < cs.size) or m.shape != (rs[r], cs[c]):
                 raise ValueError(f"block ({r}, {c}): shape {m.shape} does not match the partition")
             mats.append(m)
@@ -250,10 +254,11 @@ class Csr:
         qc = np.array([k[1] for k in keys], np.int64)
         ptrs = (C.c_void_p * max(len(mats), 1))(*[m.ctypes.data for m in mats])
         h = _vp()
-        _chk(lib().eigenex_block_upload(ctx.h, int(rs.sum()), rs.size, rs.ctypes.data_as(_lp), cs.size, cs.ctypes.data_as(_lp),
-                                        len(mats), qr.ctypes.data_as(_lp), qc.ctypes.data_as(_lp), ptrs, C.byref(h)))
+        fn = lib().eigenex_block_upload_z if cplx else lib().eigenex_block_upload
+        _chk(fn(ctx.h, int(rs.sum()), rs.size, rs.ctypes.data_as(_lp), cs.size, cs.ctypes.data_as(_lp),
+                len(mats), qr.ctypes.data_as(_lp), qc.ctypes.data_as(_lp), ptrs, C.byref(h)))
         obj = cls(ctx, h)
-        obj.is_complex = False
+        obj.is_complex = cplx
         return obj
 
     @classmethod

@@ -651,6 +651,78 @@ __global__ __launch_bounds__(kBlock) void k_block_spmv(BlockOperatorView op, con
   }
 }
 
+// complex blocks: entries, input and sums are (re, im) pairs; products without contraction and added part by
+// part, exactly like k_spmv_z
+__global__ __launch_bounds__(kBlock) void k_block_spmv_z(BlockOperatorView op, const double2* __restrict__ x_ext,
+                                                         const double* __restrict__ scale_ptr, double shift_re,
+                                                         double shift_im, double2* __restrict__ y,
+                                                         double2* __restrict__ u_out, int64_t n, int64_t ntiles,
+                                                         double* __restrict__ partials, int pstride,
+                                                         const Ctrl* __restrict__ ctrl) {
+  __shared__ double lds4[4];
+  if (ctrl->stopped) return;
+  const double scale = scale_ptr ? *scale_ptr : 1.0;
+  const bool has_shift = shift_re != 0.0 || shift_im != 0.0;
+  const double2* bval = reinterpret_cast<const double2*>(op.bval);
+  double dr = 0.0, di = 0.0;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t r = tile * kBlock + threadIdx.x;
+    if (r >= n) continue;
+    const int g = op.rowgrp[r];
+    const int gr0 = op.grow0[g], nr = op.grow0[g + 1] - gr0;
+    const int64_t ge = op.gent[g];
+    const int width = (int)((op.gent[g + 1] - ge) / nr);
+    const double2* v = bval + ge + (r - gr0);
+    const int32_t* cl = op.cols + op.gcol[g];
+    double2 sum = make_double2(0.0, 0.0);
+    int j = 0;
+    for (; j + 4 <= width; j += 4) {
+      double2 a[4], xv[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[t] = v[(int64_t)(j + t) * nr];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        xv[t] = x_ext[cl[j + t]];
+        xv[t].x *= scale, xv[t].y *= scale;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const double2 p = cmul_nofma(a[t], xv[t]);
+        sum.x = sum.x + p.x;
+        sum.y = sum.y + p.y;
+      }
+    }
+    for (; j < width; ++j) {
+      double2 xj = x_ext[cl[j]];
+      xj.x *= scale, xj.y *= scale;
+      const double2 p = cmul_nofma(v[(int64_t)j * nr], xj);
+      sum.x = sum.x + p.x;
+      sum.y = sum.y + p.y;
+    }
+    double2 xr = x_ext[r];
+    xr.x *= scale;
+    xr.y *= scale;
+    double2 yr = sum;
+    if (has_shift) {
+      const double2 t = cmul_nofma(make_double2(shift_re, shift_im), xr);
+      yr.x = yr.x + t.x;
+      yr.y = yr.y + t.y;
+    }
+    y[r] = yr;
+    if (u_out) u_out[r] = xr;
+    dr = fma(xr.x, yr.x, fma(xr.y, yr.y, dr));  // conj(u) * y
+    di = fma(xr.x, yr.y, fma(-xr.y, yr.x, di));
+  }
+  if (partials) {
+    dr = block_sum(dr, lds4);
+    di = block_sum(di, lds4);
+    if (threadIdx.x == 0) {
+      partials[blockIdx.x] = dr;
+      partials[pstride + blockIdx.x] = di;
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void k_scale(const double* __restrict__ x, const double* __restrict__ scale_dev,
                                                   double scale_host, double* __restrict__ out, int64_t n,
                                                   const Ctrl* __restrict__ ctrl) {
@@ -1061,6 +1133,14 @@ void launch_block_spmv(hipStream_t s, const BlockOperatorView& op, const double*
                        double* y, double* u_out, int64_t n, double* partials, int grid, const Ctrl* ctrl) {
   hipLaunchKernelGGL(k_block_spmv, dim3(grid), dim3(kBlock), 0, s, op, x_ext, scale, shift, y, u_out, n,
                      (n + kBlock - 1) / kBlock, partials, ctrl);
+}
+
+void launch_block_spmv_z(hipStream_t s, const BlockOperatorView& op, const double* x_ext, const double* scale, double shift_re,
+                         double shift_im, double* y, double* u_out, int64_t n, double* partials, int pstride, int grid,
+                         const Ctrl* ctrl) {
+  hipLaunchKernelGGL(k_block_spmv_z, dim3(grid), dim3(kBlock), 0, s, op, reinterpret_cast<const double2*>(x_ext), scale, shift_re,
+                     shift_im, reinterpret_cast<double2*>(y), reinterpret_cast<double2*>(u_out), n, (n + kBlock - 1) / kBlock, partials,
+                     pstride, ctrl);
 }
 
 void launch_scale(hipStream_t s, const double* x, const double* scale_dev, double scale_host, double* out, int64_t n,

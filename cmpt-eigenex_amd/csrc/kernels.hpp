@@ -69,7 +69,7 @@ enum { kPassCarry = 1, kPassNotLast = 2 };
 void launch_spmv(hipStream_t s, const int32_t* rowptr, const int32_t* col, const double* val, const double* x_ext,
                  const double* scale, double shift, double* y, double* u_out, int64_t n, double* partials, int grid,
                  const Ctrl* ctrl, int xcd_aware = 1, int pass = 0);
-// Block-sparse operator (the reference's BlockTensor<Scalar,2> layout, block_tensor.hpp:1193-1206, real fp64):
+// Block-sparse operator (the reference's BlockTensor<Scalar,2> layout, block_tensor.hpp:1193-1206, real or complex fp64):
 // 8 bytes per stored entry plus one column index per block COLUMN (4/rows bytes per entry) instead of CSR's 12.
 //   group g = the rows of one sector that this shard owns, rows grow0[g] .. grow0[g+1].  Its blocks, side by side,
 //             are one dense column-major strip rows(g) x W(g) at bval[gent[g]]; the input column of strip column j
@@ -86,6 +86,10 @@ struct BlockOperatorView {
 };
 void launch_block_spmv(hipStream_t s, const BlockOperatorView& op, const double* x_ext, const double* scale, double shift,
                        double* y, double* u_out, int64_t n, double* partials, int grid, const Ctrl* ctrl);
+// complex blocks: bval holds (re, im) pairs, gent counts entries; x/y/u_out interleaved; partials as launch_spmv_z
+void launch_block_spmv_z(hipStream_t s, const BlockOperatorView& op, const double* x_ext, const double* scale, double shift_re,
+                         double shift_im, double* y, double* u_out, int64_t n, double* partials, int pstride, int grid,
+                         const Ctrl* ctrl);
 // host-operator path: u_out = x*scale
 void launch_scale(hipStream_t s, const double* x, const double* scale_dev, double scale_host, double* out, int64_t n,
                   const Ctrl* ctrl);

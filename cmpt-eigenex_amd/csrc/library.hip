@@ -491,9 +491,9 @@ int upload_vec(eigenex_context_s* c, T** dev, const std::vector<T>& host, size_t
 
 int build_block_shard_host(eigenex_context_s* c, int64_t n_global, int gshard, const std::vector<int64_t>& ro,
                            const std::vector<int64_t>& co, const std::vector<int>& order, const int64_t* qr,
-                           const int64_t* qc, const double* const* blocks, CsrShard& s) {
+                           const int64_t* qc, const double* const* blocks, int es, CsrShard& s) {
   s.gshard = gshard;
-  s.es = 1;
+  s.es = es;
   s.blocked = true;
   partition(n_global, c->P, gshard, &s.rb, &s.re);
   s.nloc = s.re - s.rb;
@@ -536,7 +536,7 @@ int build_block_shard_host(eigenex_context_s* c, int64_t n_global, int gshard, c
     if (i1 > i0) {
       const int64_t ic = i0, nr = i1 - i0;
       grow0.push_back((int32_t)(ro[(size_t)q] + ic - s.rb));
-      gent.push_back((int64_t)bval.size());
+      gent.push_back((int64_t)bval.size() / es);
       gcol.push_back((int64_t)cols.size());
       for (int64_t p = first_of[(size_t)q]; p < first_of[(size_t)q + 1]; ++p) {
         const int k = order[(size_t)p];
@@ -551,16 +551,16 @@ int build_block_shard_host(eigenex_context_s* c, int64_t n_global, int gshard, c
           const double* src = blocks[k];
           for (int64_t j = a - A; j < pc[h][1] - A; ++j) {
             cols.push_back((int32_t)(c0 + (j - (a - A))));
-            bval.insert(bval.end(), src + j * R + ic, src + j * R + ic + nr);
+            bval.insert(bval.end(), src + (j * R + ic) * es, src + (j * R + ic + nr) * es);
           }
         }
       }
     }
   }
   const int64_t ngrp = (int64_t)grow0.size();
-  s.nnz = (int64_t)bval.size();
+  s.nnz = (int64_t)bval.size() / es;
   grow0.push_back((int32_t)s.nloc);
-  gent.push_back((int64_t)bval.size());
+  gent.push_back((int64_t)bval.size() / es);
   gcol.push_back((int64_t)cols.size());
   for (int64_t g = 0; g < ngrp; ++g)
     for (int32_t r = grow0[(size_t)g]; r < grow0[(size_t)g + 1]; ++r) rowgrp[(size_t)r] = (int32_t)g;
@@ -757,7 +757,10 @@ void launch_operator(hipStream_t st, const CsrShard* m, int es, const double* x_
                      int flags) {
   if (m->blocked) {
     const BlockOperatorView op{m->bval, m->gent, m->gcol, m->cols, m->grow0, m->rowgrp};
-    launch_block_spmv(st, op, x_ext, scale, shift, y, u_out, m->nloc, partials, grid, ctrl);
+    if (es == 2)
+      launch_block_spmv_z(st, op, x_ext, scale, shift, shift_im, y, u_out, m->nloc, partials, pstride, grid, ctrl);
+    else
+      launch_block_spmv(st, op, x_ext, scale, shift, y, u_out, m->nloc, partials, grid, ctrl);
     return;
   }
   for (int k = 0; k < m->passes; ++k) {
@@ -782,7 +785,7 @@ int enq_apply(eigenex_basis_s* b, int ucol, bool want_dot) {
     for (auto& s : b->sh) {
       CsrShard* m = s.csr;
       {
-        const double opbytes = m->blocked ? 8.0 * m->nnz + 4.0 * m->nstripcols + 4.0 * m->nloc : (4.0 + 8.0 * b->es) * m->nnz + 4.0 * (m->nloc + 1);
+        const double opbytes = m->blocked ? 8.0 * b->es * m->nnz + 4.0 * m->nstripcols + 4.0 * m->nloc : (4.0 + 8.0 * b->es) * m->nnz + 4.0 * (m->nloc + 1);
         ProfScope ps(c, EIGENEX_K_SPMV, opbytes + 32.0 * s.nd + (want_dot ? 16.0 * s.nd : 0.0));
         launch_operator(c->stream, m, b->es, s.w, &s.ctrl->scale, b->shift, b->shift_im, s.v, s.V + (int64_t)ucol * s.ldd,
                         want_dot ? s.partials : nullptr, s.pstride, s.g_spmv, s.ctrl, s.xcd_aware);
@@ -1158,9 +1161,9 @@ int eigenex_csr_upload_ex(eigenex_context_t c, int64_t n_global, int64_t row_beg
   return csr_upload_impl(c, n_global, row_begin, n_rows, rowptr, col_global, val, is_complex ? 2 : 1, column_blocks, out);
 }
 
-int eigenex_block_upload(eigenex_context_t c, int64_t n_global, int n_row_sectors, const int64_t* row_sizes, int n_col_sectors,
-                         const int64_t* col_sizes, int64_t nblocks, const int64_t* qr, const int64_t* qc,
-                         const double* const* blocks, eigenex_csr_t* out) {
+static int block_upload_impl(eigenex_context_t c, int64_t n_global, int n_row_sectors, const int64_t* row_sizes, int n_col_sectors,
+                             const int64_t* col_sizes, int64_t nblocks, const int64_t* qr, const int64_t* qc,
+                             const double* const* blocks, int es, eigenex_csr_t* out) {
   if (!c || !out || !row_sizes || !col_sizes || n_global <= 0 || n_row_sectors < 1 || n_col_sectors < 1 || nblocks < 0 ||
       (nblocks > 0 && (!qr || !qc || !blocks)) || nblocks > 2147483000)
     return fail(EIGENEX_ERR_ARG, "eigenex_block_upload: bad argument");
@@ -1188,11 +1191,11 @@ int eigenex_block_upload(eigenex_context_t c, int64_t n_global, int n_row_sector
   auto* m = new eigenex_csr_s();
   m->ctx = c;
   m->n_global = n_global;
-  m->es = 1;
+  m->es = es;
   m->sh.resize(c->local.size());
   int rc = 0;
   for (size_t i = 0; i < c->local.size() && !rc; ++i)
-    rc = build_block_shard_host(c, n_global, c->local[i], ro, co, order, qr, qc, blocks, m->sh[i]);
+    rc = build_block_shard_host(c, n_global, c->local[i], ro, co, order, qr, qc, blocks, es, m->sh[i]);
   if (!rc && c->P > 1) rc = c->loopback ? build_send_lists_loopback(c, m) : exchange_send_lists_rccl(c, n_global, m->sh[0]);
   if (rc) {
     std::string keep = g_err;
@@ -1202,6 +1205,18 @@ int eigenex_block_upload(eigenex_context_t c, int64_t n_global, int n_row_sector
   }
   *out = m;
   return 0;
+}
+
+int eigenex_block_upload(eigenex_context_t c, int64_t n_global, int n_row_sectors, const int64_t* row_sizes, int n_col_sectors,
+                         const int64_t* col_sizes, int64_t nblocks, const int64_t* qr, const int64_t* qc,
+                         const double* const* blocks, eigenex_csr_t* out) {
+  return block_upload_impl(c, n_global, n_row_sectors, row_sizes, n_col_sectors, col_sizes, nblocks, qr, qc, blocks, 1, out);
+}
+
+int eigenex_block_upload_z(eigenex_context_t c, int64_t n_global, int n_row_sectors, const int64_t* row_sizes, int n_col_sectors,
+                           const int64_t* col_sizes, int64_t nblocks, const int64_t* qr, const int64_t* qc,
+                           const double* const* blocks_interleaved, eigenex_csr_t* out) {
+  return block_upload_impl(c, n_global, n_row_sectors, row_sizes, n_col_sectors, col_sizes, nblocks, qr, qc, blocks_interleaved, 2, out);
 }
 
 int eigenex_csr_column_blocks(eigenex_csr_t m, int* passes) {

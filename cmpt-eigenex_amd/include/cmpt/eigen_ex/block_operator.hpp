@@ -7,9 +7,9 @@
 // stored blocks in map order (lexicographic {q_r, q_c}) (block_tensor.hpp:2015-2055).  Missing blocks are zero.
 //
 // BlockSparseMatrix is the same description without Eigen.  Two ways onto the device:
-//   device::blockOperator   keeps the blocks dense (eigenex_block_upload: 8 bytes per stored entry + one column
-//                           index per block column; its own kernel; real fp64) -- the default choice
-//   device::csrFromBlocks   flattens to the CSR operator (12 bytes per entry; real or complex)
+//   device::blockOperator   keeps the blocks dense (eigenex_block_upload[_z]: 8 bytes per stored real entry + one
+//                           column index per block column; its own kernel) -- the default choice
+//   device::csrFromBlocks   flattens to the CSR operator (12 bytes per real entry)
 // Both add a row's products block by block, columns ascending, and give bit-identical results.
 #pragma once
 
@@ -100,7 +100,9 @@ class BlockSparseMatrix {
 
 namespace device {
 
-inline std::shared_ptr<CsrOperator> blockOperator(std::shared_ptr<Context> ctx, const BlockSparseMatrix<double>& H) {
+namespace detail_block {
+template <class S>
+inline std::shared_ptr<CsrOperator> upload(std::shared_ptr<Context> ctx, const BlockSparseMatrix<S>& H, bool is_complex) {
   if (H.rows() != H.cols()) throw LanczosException("a Krylov operator must be square");
   std::vector<std::int64_t> rs(H.rowSizes().begin(), H.rowSizes().end()), cs(H.colSizes().begin(), H.colSizes().end());
   std::vector<std::int64_t> qr, qc;
@@ -108,13 +110,22 @@ inline std::shared_ptr<CsrOperator> blockOperator(std::shared_ptr<Context> ctx, 
   for (const auto& kv : H.blocks()) {
     qr.push_back(kv.first[0]);
     qc.push_back(kv.first[1]);
-    ptr.push_back(kv.second.data());
+    ptr.push_back(reinterpret_cast<const double*>(kv.second.data()));
   }
   eigenex_csr_t h = nullptr;
-  check(eigenex_block_upload(ctx->handle(), H.rows(), static_cast<int>(rs.size()), rs.data(), static_cast<int>(cs.size()), cs.data(),
-                             static_cast<std::int64_t>(ptr.size()), qr.data(), qc.data(), ptr.data(), &h),
+  auto fn = is_complex ? &eigenex_block_upload_z : &eigenex_block_upload;
+  check(fn(ctx->handle(), H.rows(), static_cast<int>(rs.size()), rs.data(), static_cast<int>(cs.size()), cs.data(),
+           static_cast<std::int64_t>(ptr.size()), qr.data(), qc.data(), ptr.data(), &h),
         "eigenex_block_upload");
   return CsrOperator::adopt(std::move(ctx), h);
+}
+}  // namespace detail_block
+
+inline std::shared_ptr<CsrOperator> blockOperator(std::shared_ptr<Context> ctx, const BlockSparseMatrix<double>& H) {
+  return detail_block::upload(std::move(ctx), H, false);
+}
+inline std::shared_ptr<CsrOperator> blockOperator(std::shared_ptr<Context> ctx, const BlockSparseMatrix<std::complex<double>>& H) {
+  return detail_block::upload(std::move(ctx), H, true);
 }
 
 inline std::shared_ptr<CsrOperator> csrFromBlocks(std::shared_ptr<Context> ctx, const BlockSparseMatrix<double>& H) {

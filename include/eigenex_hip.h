@@ -144,10 +144,11 @@ int eigenex_csr_upload_z(eigenex_context_t ctx, int64_t n_global, int64_t row_be
 int eigenex_csr_upload_ex(eigenex_context_t ctx, int64_t n_global, int64_t row_begin, int64_t n_rows,
                           const int32_t* rowptr, const int32_t* col_global, const double* val, int is_complex,
                           int column_blocks, eigenex_csr_t* out);
-/* Block-sparse operator in the reference's BlockTensor<Scalar,2> layout (block_tensor.hpp:1193-1206; real fp64):
+/* Block-sparse operator in the reference's BlockTensor<Scalar,2> layout (block_tensor.hpp:1193-1206):
  * one direct-sum partition per axis (row_sizes / col_sizes, both adding up to n_global) and dense column-major
  * blocks, block k = sector (qr[k], qc[k]) with leading dimension row_sizes[qr[k]]; absent blocks are zero, an index
- * pair may appear once.  Kept on the device as dense blocks (8 bytes per stored entry, no per-entry index) and
+ * pair may appear once.  Kept on the device as dense blocks (8 bytes per stored real entry + one column index per
+ * block column, no per-entry index) and
  * applied by its own kernel with the summation order of the flattened CSR rows (block by block, columns
  * ascending), i.e. bit-identical to eigenex_csr_upload of the same matrix.  Every rank passes at least the blocks
  * of the sector rows that intersect its rows (others are ignored).  Collective in RCCL mode.  The handle is used
@@ -155,6 +156,10 @@ int eigenex_csr_upload_ex(eigenex_context_t ctx, int64_t n_global, int64_t row_b
 int eigenex_block_upload(eigenex_context_t ctx, int64_t n_global, int n_row_sectors, const int64_t* row_sizes,
                          int n_col_sectors, const int64_t* col_sizes, int64_t nblocks, const int64_t* qr,
                          const int64_t* qc, const double* const* blocks, eigenex_csr_t* out);
+/* the same with complex blocks: (re, im) pairs, leading dimension row_sizes[qr[k]] entries */
+int eigenex_block_upload_z(eigenex_context_t ctx, int64_t n_global, int n_row_sectors, const int64_t* row_sizes,
+                           int n_col_sectors, const int64_t* col_sizes, int64_t nblocks, const int64_t* qr,
+                           const int64_t* qc, const double* const* blocks_interleaved, eigenex_csr_t* out);
 /* passes of the (largest) local shard: 1 = not column-blocked */
 int eigenex_csr_column_blocks(eigenex_csr_t csr, int* passes);
 /* synthetic 7-point Laplacian on an n^3 grid generated on the device (BASELINE configs 2 and 4) */

@@ -247,3 +247,60 @@ def test_block_operator_lanczos_matches_csr_operator(mods):
     ref = cref.CLanczos(rowptr, col, val, init, cap=41)
     ref.run(40)
     np.testing.assert_allclose(out[1][1], ref.alpha[:40], rtol=0, atol=1e-11)
+
+
+def _flatten_blocks(rs, cs, blocks, dtype):
+    """rows of the block matrix in stored order: block by block (ascending block column), columns ascending"""
+    ro = np.concatenate([[0], np.cumsum(rs)])
+    co = np.concatenate([[0], np.cumsum(cs)])
+    rowptr, col, val = [0], [], []
+    for qr in range(len(rs)):
+        keys = sorted(k for k in blocks if k[0] == qr)
+        for i in range(rs[qr]):
+            for (_, qc) in keys:
+                col.extend(range(co[qc], co[qc + 1]))
+                val.extend(blocks[(qr, qc)][i, :])
+            rowptr.append(len(col))
+    return np.array(rowptr, np.int32), np.array(col, np.int32), np.array(val, dtype)
+
+
+@pytest.mark.parametrize("shards", [1, 3])
+def test_complex_block_operator(mods, shards):
+    """eigenex_block_upload_z: complex dense blocks; output bit-identical to k_spmv_z on the flattened rows (same
+    products, same order), Hermitian Lanczos through both forms agrees to rounding."""
+    capi, solver = mods
+    rng = np.random.default_rng(91)
+    sizes = [5, 1, 0, 33, 12, 260, 7, 64]
+    N = sum(sizes)
+    blocks = {}
+    for q in range(len(sizes)):
+        if sizes[q] == 0:
+            continue
+        D = rng.standard_normal((sizes[q], sizes[q])) + 1j * rng.standard_normal((sizes[q], sizes[q]))
+        blocks[(q, q)] = (D + D.conj().T) / 2
+        p = (3 * q + 2) % len(sizes)
+        if p != q and sizes[p] > 0 and (q, p) not in blocks:
+            B = 0.3 * (rng.standard_normal((sizes[q], sizes[p])) + 1j * rng.standard_normal((sizes[q], sizes[p])))
+            blocks[(q, p)] = B
+            blocks[(p, q)] = B.conj().T.copy()
+    rowptr, col, val = _flatten_blocks(sizes, sizes, blocks, np.complex128)
+    x = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    ctx = capi.Context(loopback_shards=shards) if shards > 1 else capi.Context()
+    outs = []
+    for A in (capi.Csr.upload(ctx, N, rowptr, col, val), capi.Csr.upload_blocks(ctx, sizes, sizes, blocks)):
+        assert A.is_complex and A.info()["nnz_local"] == rowptr[-1]
+        b = capi.Basis(ctx, A, N, 31, dtype=np.complex128)
+        b.upload(capi.VEC_W, x)
+        b.apply(capi.VEC_W, capi.VEC_V, 0.0)
+        y = b.download(capi.VEC_V)
+        b.upload(capi.VEC_W, x)
+        b.lanczos_enqueue(30)
+        st, al, be = b.lanczos_state()
+        outs.append((y, al.copy(), be.copy()))
+        b.close()
+        A.close()
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_allclose(outs[1][0], ko.block_sparse_matmul(sizes, sizes, blocks)(x), rtol=0, atol=1e-11)
+    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(outs[0][2], outs[1][2], rtol=0, atol=1e-12)
+    ctx.close()
