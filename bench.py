@@ -201,6 +201,12 @@ def main():
                 cores = min(cref.max_threads(), len(os.sched_getaffinity(0)))
             except AttributeError:
                 cores = cref.max_threads()
+            try:  # a container's CPU share (cgroup v2 quota) is often far below the host's core count
+                quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+                if quota != "max":
+                    cores = max(1, min(cores, int(int(quota) / int(period))))
+            except (OSError, ValueError):
+                pass
             sn, sm = 256, 8  # 11 vectors x 134 MB + 1.4 GB CSR: well beyond the host's last-level cache
             one = cpu_baseline(sn, sm, 1)
             allc = cpu_baseline(256, 16, cores)
