@@ -70,6 +70,7 @@ std::array<double, 2> estimateEigenvalueRange(Index n, Index count, const Index*
   std::vector<Scalar> centre(static_cast<std::size_t>(n), Scalar(0.0));
   std::vector<double> radius(static_cast<std::size_t>(n), 0.0);
   for (Index t = 0; t < count; ++t) {
+    if (rows[t] < 0 || rows[t] >= n || cols[t] < 0 || cols[t] >= n) throw LanczosException("triplet index out of range");
     if (rows[t] == cols[t]) centre[static_cast<std::size_t>(rows[t])] += vals[t];
     else radius[static_cast<std::size_t>(rows[t])] += std::abs(vals[t]);
   }

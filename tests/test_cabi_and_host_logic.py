@@ -210,3 +210,23 @@ def test_blocks_to_csr_matches_blocktensor_contraction(built):
     np.testing.assert_allclose(v2.reshape(3, 2), 3 * B)
     with pytest.raises(Exception):
         solver.blocks_to_csr([3], [2], {(0, 0): np.zeros((2, 2))})
+
+
+def test_host_logic_under_sanitizers(built, tmp_path):
+    """The CPU-side code of the header-only layer (small dense eigensolvers, COO / block ingestion, containers, error
+    paths) compiled with AddressSanitizer + UBSan and run; device code cannot be sanitised on the GPU pool."""
+    import shutil
+    import subprocess
+
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    exe = str(tmp_path / "host_logic_sanitize")
+    lib = os.path.join(ROOT, "cmpt-eigenex_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I",
+                           os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "cmpt-eigenex_amd", "include"),
+                           os.path.join(ROOT, "tests", "cpp", "host_logic_sanitize.cpp"), "-o", exe, "-L", lib, "-leigenex_hip",
+                           "-Wl,-rpath," + lib])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")  # the HIP runtime's own start-up allocations are not ours to judge
+    out = subprocess.run([exe], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    assert b"all checks passed" in out.stdout
