@@ -382,9 +382,9 @@ __device__ __forceinline__ double2 nt_ld_d2(const double* p) {
 struct TileRange {
   int64_t first, step, end;
 };
-__device__ __forceinline__ TileRange spmv_tiles(int64_t ntiles, int xcd_aware) {
+__device__ __forceinline__ TileRange spmv_tiles(int64_t ntiles, int xcd_contiguous) {
   const int64_t G = gridDim.x, b = blockIdx.x;
-  if (xcd_aware && (G & 7) == 0) {
+  if (xcd_contiguous && (G & 7) == 0) {
     const int64_t chunk = (ntiles + 7) >> 3, x = b & 7, j = b >> 3;
     const int64_t lo = x * chunk, hi = lo + chunk < ntiles ? lo + chunk : ntiles;
     return TileRange{lo + j, G >> 3, hi};
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int32_t* __restrict__ row
                                                  const double* __restrict__ val, const double* __restrict__ x_ext,
                                                  const double* __restrict__ scale_ptr, double shift,
                                                  double* __restrict__ y, double* __restrict__ u_out, int64_t n,
-                                                 int64_t ntiles, double* __restrict__ partials, int xcd_aware,
+                                                 int64_t ntiles, double* __restrict__ partials, int spmv_flags,
                                                  int pass, const Ctrl* __restrict__ ctrl) {
   __shared__ double prod[kSpmvChunk + kSpmvChunk / 32 + 8];
   __shared__ double lds4[4];
@@ -404,8 +404,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int32_t* __restrict__ row
   const double scale = scale_ptr ? *scale_ptr : 1.0;
   const int tid = threadIdx.x;
   double dot = 0.0;
-  const bool nt = (xcd_aware & 2) != 0;  // flags: bit 0 = XCD-contiguous tiles, bit 1 = non-temporal val/col loads
-  const TileRange tr = spmv_tiles(ntiles, xcd_aware & 1);
+  const bool nt = (spmv_flags & 2) != 0;  // flags: bit 0 = XCD-contiguous tiles, bit 1 = non-temporal val/col loads
+  const TileRange tr = spmv_tiles(ntiles, spmv_flags & 1);
   // row pointers of a tile: fetched one tile ahead, so that their latency is not part of the chain
   // rowptr -> val/col -> x that every tile otherwise pays in sequence
   auto tile_rows = [&](int64_t tile, int& rs, int& re, int& p0, int& p1) {
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_z(const int32_t* __restrict__ r
                                                    const double* __restrict__ scale_ptr, double shift_re,
                                                    double shift_im, double2* __restrict__ y,
                                                    double2* __restrict__ u_out, int64_t n, int64_t ntiles,
-                                                   double* __restrict__ partials, int pstride, int xcd_aware,
+                                                   double* __restrict__ partials, int pstride, int spmv_flags,
                                                    int pass, const Ctrl* __restrict__ ctrl) {
   __shared__ double2 prod[kSpmvChunkZ + kSpmvChunkZ / 16 + 8];
   __shared__ double lds4[4];
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_z(const int32_t* __restrict__ r
   const int tid = threadIdx.x;
   const bool has_shift = shift_re != 0.0 || shift_im != 0.0;
   double dr = 0.0, di = 0.0;
-  const TileRange tr = spmv_tiles(ntiles, xcd_aware & 1);
+  const TileRange tr = spmv_tiles(ntiles, spmv_flags & 1);
   for (int64_t tile = tr.first; tile < tr.end; tile += tr.step) {
     const int64_t r0 = tile * kSpmvRows;
     const int64_t r = r0 + tid;
@@ -1102,11 +1102,11 @@ void launch_update(hipStream_t s, const double* src, double* dst, ThreeTerm tt, 
 
 void launch_spmv_z(hipStream_t s, const int32_t* rowptr, const int32_t* col, const double* val, const double* x_ext,
                    const double* scale, double shift_re, double shift_im, double* y, double* u_out, int64_t n,
-                   double* partials, int pstride, int grid, const Ctrl* ctrl, int xcd_aware, int pass) {
+                   double* partials, int pstride, int grid, const Ctrl* ctrl, int spmv_flags, int pass) {
   const int64_t ntiles = (n + kSpmvRows - 1) / kSpmvRows;
   hipLaunchKernelGGL(k_spmv_z, dim3(grid), dim3(kBlock), 0, s, rowptr, col, reinterpret_cast<const double2*>(val),
                      reinterpret_cast<const double2*>(x_ext), scale, shift_re, shift_im, reinterpret_cast<double2*>(y),
-                     reinterpret_cast<double2*>(u_out), n, ntiles, partials, pstride, xcd_aware, pass, ctrl);
+                     reinterpret_cast<double2*>(u_out), n, ntiles, partials, pstride, spmv_flags, pass, ctrl);
 }
 
 void launch_shift_dot_z(hipStream_t s, double* y, const double* u, double shift_re, double shift_im, int64_t n,
@@ -1123,10 +1123,10 @@ void launch_reduce(hipStream_t s, const double* partials, int pstride, int nbloc
 
 void launch_spmv(hipStream_t s, const int32_t* rowptr, const int32_t* col, const double* val, const double* x_ext,
                  const double* scale, double shift, double* y, double* u_out, int64_t n, double* partials, int grid,
-                 const Ctrl* ctrl, int xcd_aware, int pass) {
+                 const Ctrl* ctrl, int spmv_flags, int pass) {
   const int64_t ntiles = (n + kSpmvRows - 1) / kSpmvRows;
   hipLaunchKernelGGL(k_spmv, dim3(grid), dim3(kBlock), 0, s, rowptr, col, val, x_ext, scale, shift, y, u_out, n,
-                     ntiles, partials, xcd_aware, pass, ctrl);
+                     ntiles, partials, spmv_flags, pass, ctrl);
 }
 
 void launch_block_spmv(hipStream_t s, const BlockOperatorView& op, const double* x_ext, const double* scale, double shift,

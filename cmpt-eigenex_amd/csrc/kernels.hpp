@@ -56,7 +56,7 @@ void launch_update(hipStream_t s, const double* src, double* dst, ThreeTerm tt, 
 // complex operator: n = rows; val/x/y/u_out interleaved (re, im); partials[block] = re, partials[pstride+block] = im of conj(u).y
 void launch_spmv_z(hipStream_t s, const int32_t* rowptr, const int32_t* col, const double* val, const double* x_ext,
                    const double* scale, double shift_re, double shift_im, double* y, double* u_out, int64_t n,
-                   double* partials, int pstride, int grid, const Ctrl* ctrl, int xcd_aware = 1, int pass = 0);
+                   double* partials, int pstride, int grid, const Ctrl* ctrl, int spmv_flags = 0, int pass = 0);
 void launch_shift_dot_z(hipStream_t s, double* y, const double* u, double shift_re, double shift_im, int64_t n,
                         double* partials, int pstride, int grid, const Ctrl* ctrl);
 // out[c] = sum_b partials[c*pstride + b], fixed order (deterministic second stage)
@@ -68,7 +68,7 @@ void launch_reduce(hipStream_t s, const double* partials, int pstride, int nbloc
 enum { kPassCarry = 1, kPassNotLast = 2 };
 void launch_spmv(hipStream_t s, const int32_t* rowptr, const int32_t* col, const double* val, const double* x_ext,
                  const double* scale, double shift, double* y, double* u_out, int64_t n, double* partials, int grid,
-                 const Ctrl* ctrl, int xcd_aware = 1, int pass = 0);
+                 const Ctrl* ctrl, int spmv_flags = 0, int pass = 0);
 // Block-sparse operator (the reference's BlockTensor<Scalar,2> layout, block_tensor.hpp:1193-1206, real or complex fp64):
 // 8 bytes per stored entry plus one column index per block COLUMN (4/rows bytes per entry) instead of CSR's 12.
 //   group g = the rows of one sector that this shard owns, rows grow0[g] .. grow0[g+1].  Its blocks, side by side,

@@ -143,6 +143,20 @@ int prof_collect(eigenex_context_s* c) {
   return 0;
 }
 
+// device scratch that must not outlive the call, also when an error path returns early
+template <class T>
+struct DeviceTemp {
+  T* p = nullptr;
+  DeviceTemp() = default;
+  DeviceTemp(const DeviceTemp&) = delete;
+  DeviceTemp& operator=(const DeviceTemp&) = delete;
+  ~DeviceTemp() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t alloc(size_t count) { return hipMalloc(&p, sizeof(T) * (count ? count : 1)); }
+  operator T*() const { return p; }
+};
+
 struct Segment {  // one contiguous piece of a halo exchange with one peer
   int peer;       // global shard id
   int64_t offset; // recv: offset into the halo region; send: offset into send_idx / sendbuf
@@ -194,7 +208,7 @@ struct BasisShard {
   double* X = nullptr;  // Ritz vector scratch (ldv x 8), lazy
   Ctrl* ctrl = nullptr;
   Ctrl* ctrl_zero = nullptr;  // always-zero control block for the stand-alone primitives
-  int g_vec = 1, g_spmv = 1, pstride = 1, xcd_aware = 0;  // XCD-contiguous SpMV tiles measured 7 % slower at 512^3
+  int g_vec = 1, g_spmv = 1, pstride = 1, spmv_flags = 0;  // XCD-contiguous SpMV tiles measured 7 % slower at 512^3
 };
 
 }  // namespace
@@ -581,9 +595,9 @@ int exchange_send_lists_rccl(eigenex_context_s* c, int64_t /*n_global*/, CsrShar
   const int P = c->P;
   std::vector<int32_t> need_cnt((size_t)P, 0);
   for (auto& rg : s.recv) need_cnt[rg.peer] = (int32_t)rg.count;
-  int32_t *d_cnt = nullptr, *d_all = nullptr;
-  HIPCHK(hipMalloc(&d_cnt, sizeof(int32_t) * P));
-  HIPCHK(hipMalloc(&d_all, sizeof(int32_t) * P * P));
+  DeviceTemp<int32_t> d_cnt, d_all, d_need, d_req;
+  HIPCHK(d_cnt.alloc((size_t)P));
+  HIPCHK(d_all.alloc((size_t)P * P));
   HIPCHK(hipMemcpyAsync(d_cnt, need_cnt.data(), sizeof(int32_t) * P, hipMemcpyHostToDevice, c->stream));
   NCCLCHK(ncclAllGather(d_cnt, d_all, (size_t)P, ncclInt32, c->comm, c->stream));
   std::vector<int32_t> all((size_t)P * P);
@@ -593,12 +607,11 @@ int exchange_send_lists_rccl(eigenex_context_s* c, int64_t /*n_global*/, CsrShar
   int64_t nrecv_total = 0;
   for (int r = 0; r < P; ++r)
     if (r != c->rank) nrecv_total += all[(size_t)r * P + c->rank];
-  int32_t *d_need = nullptr, *d_req = nullptr;
   if (s.nhalo) {
-    HIPCHK(hipMalloc(&d_need, sizeof(int32_t) * s.nhalo));
+    HIPCHK(d_need.alloc((size_t)s.nhalo));
     HIPCHK(hipMemcpyAsync(d_need, s.halo_cols.data(), sizeof(int32_t) * s.nhalo, hipMemcpyHostToDevice, c->stream));
   }
-  if (nrecv_total) HIPCHK(hipMalloc(&d_req, sizeof(int32_t) * nrecv_total));
+  if (nrecv_total) HIPCHK(d_req.alloc((size_t)nrecv_total));
   NCCLCHK(ncclGroupStart());
   for (auto& rg : s.recv)
     NCCLCHK(ncclSend(d_need + rg.offset, (size_t)rg.count, ncclInt32, rg.peer, c->comm, c->stream));
@@ -620,12 +633,7 @@ int exchange_send_lists_rccl(eigenex_context_s* c, int64_t /*n_global*/, CsrShar
     CHK(add_send(s, r, req.data() + off, cnt, idx_host));
     off += cnt;
   }
-  CHK(finish_send(c, s, idx_host));
-  (void)hipFree(d_cnt);
-  (void)hipFree(d_all);
-  if (d_need) (void)hipFree(d_need);
-  if (d_req) (void)hipFree(d_req);
-  return 0;
+  return finish_send(c, s, idx_host);
 }
 
 int build_send_lists_loopback(eigenex_context_s* c, eigenex_csr_s* m) {
@@ -788,7 +796,7 @@ int enq_apply(eigenex_basis_s* b, int ucol, bool want_dot) {
         const double opbytes = m->blocked ? 8.0 * b->es * m->nnz + 4.0 * m->nstripcols + 4.0 * m->nloc : (4.0 + 8.0 * b->es) * m->nnz + 4.0 * (m->nloc + 1);
         ProfScope ps(c, EIGENEX_K_SPMV, opbytes + 32.0 * s.nd + (want_dot ? 16.0 * s.nd : 0.0));
         launch_operator(c->stream, m, b->es, s.w, &s.ctrl->scale, b->shift, b->shift_im, s.v, s.V + (int64_t)ucol * s.ldd,
-                        want_dot ? s.partials : nullptr, s.pstride, s.g_spmv, s.ctrl, s.xcd_aware);
+                        want_dot ? s.partials : nullptr, s.pstride, s.g_spmv, s.ctrl, s.spmv_flags);
       }
       if (want_dot) {
         ProfScope ps(c, EIGENEX_K_SMALL, 0.0);
@@ -1450,7 +1458,7 @@ int eigenex_basis_tune(eigenex_basis_t b, int vec_blocks_per_cu, int spmv_blocks
   for (auto& s : b->sh) {
     s.g_vec = grid_for_tiles((s.nd + kTileRows - 1) / kTileRows, vec_blocks_per_cu);
     s.g_spmv = grid_for_tiles((s.nloc + kSpmvRows - 1) / kSpmvRows, spmv_blocks_per_cu);
-    s.xcd_aware = flags & 3;  // bit 0: XCD-contiguous tiles, bit 1: non-temporal val/col loads
+    s.spmv_flags = flags & 3;  // bit 0: XCD-contiguous tiles, bit 1: non-temporal val/col loads
   }
   return 0;
 }
@@ -1621,7 +1629,7 @@ int eigenex_apply(eigenex_basis_t b, int x_ref, int y_ref, double shift, double*
     CsrShard* m = s.csr;
     ProfScope ps(c, EIGENEX_K_SPMV, (4.0 + 8.0 * b->es) * m->nnz + 4.0 * (m->nloc + 1) + 16.0 * s.nd);
     launch_operator(c->stream, m, b->es, s.w, nullptr, shift, 0.0, vec_ptr(s, b->cap, b->nq, y_ref), nullptr,
-                    dot ? s.partials : nullptr, s.pstride, s.g_spmv, s.ctrl_zero, s.xcd_aware);
+                    dot ? s.partials : nullptr, s.pstride, s.g_spmv, s.ctrl_zero, s.spmv_flags);
     if (dot) launch_reduce(c->stream, s.partials, s.pstride, s.g_spmv, b->es, s.hbuf + b->slot_alpha(), s.ctrl_zero);
   }
   if (dot) {

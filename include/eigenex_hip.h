@@ -27,6 +27,9 @@
  *     kernels, halo lists and reduction points, device copies instead of RCCL).
  *   - host pointers passed to upload/download calls cover the rows this context
  *     owns: one shard in RCCL mode, all rows in loopback mode.
+ *   - threading: like the reference's solver objects, handles are not thread-safe: use a context and
+ *     everything created from it from one host thread at a time (eigenex_last_error() is per thread);
+ *     different contexts may be driven from different threads.
  */
 #ifndef EIGENEX_HIP_H
 #define EIGENEX_HIP_H

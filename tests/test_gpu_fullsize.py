@@ -190,3 +190,43 @@ def test_config4_eight_row_shards_match_single_shard(capi):
     np.testing.assert_allclose(res[0][0], res[1][0], rtol=0, atol=1e-12)
     np.testing.assert_allclose(res[0][1], res[1][1], rtol=0, atol=1e-12)
     assert np.abs(res[0][2] - res[1][2]).max() < 1e-12
+
+
+def test_largest_laplacian_two_shards_768(capi):
+    """Maximum sizes: 768^3 = 4.5e8 rows, 3.2e9 stored entries (more than int32 can count: two row shards of
+    1.6e9 each, the per-shard limit), 3.6 GB per Krylov vector, ~120 GB on the device.  Checks 64-bit offsets in the
+    generator, the kernels and the halo plan through size-independent properties: alpha_0 by hand, beta > 0,
+    orthonormality of the basis, Ritz values inside the analytic spectrum, the Lanczos relation."""
+    n, m = 768, 8
+    N = n ** 3
+    ctx = capi.Context(loopback_shards=2)
+    try:
+        A = capi.Csr.laplacian3d(ctx, n)
+        b = capi.Basis(ctx, A, N, m + 1)
+    except capi.EigenexError as e:  # pragma: no cover
+        pytest.skip(f"not enough device memory for 768^3: {e}")
+    info = A.info()
+    assert info["nnz_local"] == 7 * N - 6 * n * n > 2 ** 31 and info["n_halo_local"] == 2 * n * n
+    init = np.random.default_rng(7).standard_normal(N)
+    b.upload(capi.VEC_W, init)
+    b.lanczos_enqueue(m + 1)
+    st, alpha, beta = b.lanczos_state()
+    assert (st.nvec, st.iterations, st.stopped) == (m + 1, m, 0)
+    assert np.all(beta > 0)
+    th = ko.tridiagonal_eigh(alpha, beta, vectors=False)[0]
+    assert 3 * (2 - 2 * np.cos(np.pi / (n + 1))) <= th[0] and th[-1] <= 3 * (2 - 2 * np.cos(n * np.pi / (n + 1)))
+    for c in (0, m):
+        g = b.dots(capi.VEC_COL(c), 0, 1, m + 1)
+        g[c] -= 1.0
+        assert np.abs(g).max() < 1e-12
+    assert _lanczos_relation_residual(capi, b, m - 1, alpha, beta) < 1e-12 * 12.0
+    u0 = b.download(capi.VEC_COL(0))
+    nrm = np.sqrt(np.dot(init, init))
+    assert np.abs(u0 - init / nrm).max() < 1e-15
+    g3 = u0.reshape(n, n, n)
+    a0 = 6.0 * np.dot(u0, u0) - 2.0 * (np.einsum("ijk,ijk->", g3[1:], g3[:-1]) + np.einsum("ijk,ijk->", g3[:, 1:], g3[:, :-1])
+                                       + np.einsum("ijk,ijk->", g3[:, :, 1:], g3[:, :, :-1]))
+    assert abs(alpha[0] - a0) < 1e-11
+    b.close()
+    A.close()
+    ctx.close()
