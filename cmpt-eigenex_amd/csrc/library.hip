@@ -1433,6 +1433,10 @@ int eigenex_basis_create_ex(eigenex_context_t c, eigenex_csr_t csr, int64_t n_gl
       HIPCHK(hipMemsetAsync(s.ctrl, 0, sizeof(Ctrl), c->stream));
       HIPCHK(hipMemsetAsync(s.ctrl_zero, 0, sizeof(Ctrl), c->stream));
     }
+    if (std::getenv("EIGENEX_DEBUG_POINTERS"))  // allocation placement, for timing investigations
+      for (auto& s : b->sh)
+        std::fprintf(stderr, "eigenex: shard %d V=%p (stride %lld B) v=%p w=%p start=%p partials=%p\n", s.gshard, (void*)s.V,
+                     (long long)(s.ldd * 8), (void*)s.v, (void*)s.w, (void*)s.start, (void*)s.partials);
     HIPCHK(hipHostMalloc(&b->pin_ctrl, sizeof(Ctrl)));
     if (!csr) {
       HIPCHK(hipHostMalloc(&b->pin_in, sizeof(double) * (size_t)b->sh[0].ldd));
