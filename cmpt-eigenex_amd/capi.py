@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -72,6 +73,7 @@ SIGNATURES = {
     "eigenex_csr_destroy": (C.c_int, [_vp]),
     "eigenex_csr_upload_ex": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int64, _ip, _ip, _dp, C.c_int, C.c_int, C.POINTER(_vp)]),
     "eigenex_csr_column_blocks": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "eigenex_csr_upload_device": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, C.c_int, C.POINTER(_vp)]),
     "eigenex_block_upload": (C.c_int, [_vp, C.c_int64, C.c_int, _lp, C.c_int, _lp, C.c_int64, _lp, _lp, C.POINTER(C.c_void_p), C.POINTER(_vp)]),
     "eigenex_block_upload_z": (C.c_int, [_vp, C.c_int64, C.c_int, _lp, C.c_int, _lp, C.c_int64, _lp, _lp, C.POINTER(C.c_void_p), C.POINTER(_vp)]),
     "eigenex_csr_info": (C.c_int, [_vp, _lp, _lp, _lp, _lp]),
@@ -107,6 +109,23 @@ SIGNATURES = {
 _LIB = None
 
 
+def _preload_torch_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / librccl.so.1 (ROCm 7.0 here) under the same SONAMEs as
+    the system ROCm this library is linked against.  Whichever copy is loaded first serves both: torch first is
+    fine (this library then runs on torch's runtime; that is how bench.py and the tests run), this library first makes
+    torch mix runtimes and abort at exit ("double free or corruption").  So when torch is installed it is imported
+    before the library is loaded.  EIGENEX_NO_TORCH_PRELOAD=1 skips this for processes that never import torch."""
+    if "torch" in sys.modules or os.environ.get("EIGENEX_NO_TORCH_PRELOAD"):
+        return
+    import importlib.util
+
+    if importlib.util.find_spec("torch") is not None:
+        try:
+            import torch  # noqa: F401
+        except Exception:  # a broken torch install must not keep the library from loading
+            pass
+
+
 def lib():
     """Load libeigenex_hip.so (built in-tree by cmpt_eigenex_amd.build).  Fails loudly if missing."""
     global _LIB
@@ -115,6 +134,7 @@ def lib():
             raise EigenexError(
                 f"{LIB_PATH} is missing: build it with `python -m cmpt_eigenex_amd.build` "
                 "(there is no CPU fallback for the Krylov hot path)")
+        _preload_torch_runtime()
         L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
@@ -233,6 +253,16 @@ class Csr:
             _chk(lib().eigenex_csr_upload(ctx.h, n_global, row_begin, rp.size - 1, _i(rp), _i(cl), vp, C.byref(h)))
         obj = cls(ctx, h)
         obj.is_complex = bool(np.iscomplexobj(val))
+        return obj
+
+    @classmethod
+    def from_device(cls, ctx: Context, n: int, rowptr_ptr: int, col_ptr: int, val_ptr: int, is_complex: bool = False):
+        """eigenex_csr_upload_device: CSR arrays already on this GPU, given as raw device addresses
+        (e.g. torch tensors' .data_ptr(): int32 rowptr[n+1], int32 col[nnz], float64/complex128 val[nnz])."""
+        h = _vp()
+        _chk(lib().eigenex_csr_upload_device(ctx.h, n, _vp(rowptr_ptr), _vp(col_ptr), _vp(val_ptr), int(is_complex), C.byref(h)))
+        obj = cls(ctx, h)
+        obj.is_complex = bool(is_complex)
         return obj
 
     @classmethod

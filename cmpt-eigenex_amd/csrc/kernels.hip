@@ -15,6 +15,7 @@
 // re-reads are served by L2 / Infinity Cache.
 #include "kernels.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace eigenex {
@@ -875,6 +876,24 @@ __global__ void k_accept_vector(Ctrl* ctrl) {
   ctrl->nvec++;
 }
 
+// ---- validation of a CSR handed over in device memory (eigenex_csr_upload_device) -----------------
+// bad[0] += rows whose row pointers decrease or leave [0, nnz]; bad[1] += column indices outside [0, ncols)
+__global__ __launch_bounds__(kBlock) void k_check_csr(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                      int64_t n, int64_t nnz, int64_t ncols, unsigned int* __restrict__ bad) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  unsigned int b0 = 0, b1 = 0;
+  for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += stride) {
+    const int64_t a = rowptr[r], e = rowptr[r + 1];
+    if (a < 0 || e < a || e > nnz) ++b0;
+  }
+  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < nnz; p += stride) {
+    const int64_t c = col[p];
+    if (c < 0 || c >= ncols) ++b1;
+  }
+  if (b0) atomicAdd(bad, b0);
+  if (b1) atomicAdd(bad + 1, b1);
+}
+
 // ---- synthetic operator ------------------------------------------------------
 // number of stored entries in rows [0, i) of the n^3 7-point Dirichlet Laplacian
 __device__ __forceinline__ int64_t lap_prefix(int64_t i, int64_t n) {
@@ -1210,6 +1229,11 @@ void launch_ritz(hipStream_t s, const double* V, int64_t ldv, int nvec, const do
     hipLaunchKernelGGL((k_ritz<16, false>), dim3(grid), dim3(kBlock), 0, s, V, ldv, nvec, St_dev, nev, X, ldx, n, ntiles, partials, pstride);
   else
     hipLaunchKernelGGL((k_ritz<8, true>), dim3(grid), dim3(kBlock), 0, s, V, ldv, nvec, St_dev, nev, X, ldx, n, ntiles, partials, pstride);
+}
+
+void launch_check_csr(hipStream_t s, const int32_t* rowptr, const int32_t* col, int64_t n, int64_t nnz, int64_t ncols, unsigned int* bad) {
+  const int grid = grid_for_tiles((std::max<int64_t>(n, nnz) + kBlock - 1) / kBlock, 8);
+  hipLaunchKernelGGL(k_check_csr, dim3(grid), dim3(kBlock), 0, s, rowptr, col, n, nnz, ncols, bad);
 }
 
 void launch_first_nonzero(hipStream_t s, const double* X, int64_t ldx, int ncol, int64_t n, int es, double* out) {

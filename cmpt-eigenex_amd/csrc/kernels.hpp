@@ -124,6 +124,8 @@ void launch_restart_fix(hipStream_t s, Ctrl* ctrl, double* alpha, double* beta, 
 // vector accepted into the basis: ++nvec  (after the operator has been applied with `scale`)
 void launch_accept_vector(hipStream_t s, Ctrl* ctrl);
 
+// counts malformed row pointers (bad[0]) and out-of-range columns (bad[1]) of a device-resident CSR
+void launch_check_csr(hipStream_t s, const int32_t* rowptr, const int32_t* col, int64_t n, int64_t nnz, int64_t ncols, unsigned int* bad);
 // synthetic 7-point Laplacian rows [rb, re) of an n^3 grid; cols remapped to local/halo numbering
 void launch_laplacian3d(hipStream_t s, int64_t n, int64_t rb, int64_t re, int64_t lower_start, int64_t n_lower,
                         int64_t halo_base, int32_t* rowptr, int32_t* col, double* val);

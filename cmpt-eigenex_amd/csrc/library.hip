@@ -27,12 +27,16 @@ int fail(int code, const std::string& msg) {
   return code;
 }
 
+// A failed HIP call also sets the runtime's sticky per-thread "last error"; a framework sharing the runtime (torch
+// checks hipGetLastError() after its own calls) would report it as its own failure later, so it is cleared here.
 #define HIPCHK(expr)                                                                                   \
   do {                                                                                                 \
     hipError_t e_ = (expr);                                                                            \
-    if (e_ != hipSuccess)                                                                              \
+    if (e_ != hipSuccess) {                                                                            \
+      (void)hipGetLastError();                                                                         \
       return fail(EIGENEX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" + __FILE__ + ":" + \
                                        std::to_string(__LINE__) + ")");                                \
+    }                                                                                                  \
   } while (0)
 
 #define NCCLCHK(expr)                                                                                    \
@@ -1004,6 +1008,7 @@ int eigenex_context_create(int device, int rank, int world_size, const void* rcc
     ncclUniqueId id;
     std::memcpy(&id, rccl_id128, sizeof(id));
     ncclResult_t r = ncclCommInitRank(&c->comm, world_size, id, rank);
+    (void)hipGetLastError();  // RCCL's topology probing leaves a sticky "invalid device ordinal" behind (see HIPCHK)
     if (r != ncclSuccess) {
       std::string m = std::string("ncclCommInitRank: ") + ncclGetErrorString(r);
       (void)hipStreamDestroy(c->stream);
@@ -1081,6 +1086,7 @@ int eigenex_context_destroy(eigenex_context_t c) {
   }
   if (c->comm) (void)ncclCommDestroy(c->comm);
   (void)hipStreamDestroy(c->stream);
+  (void)hipGetLastError();
   delete c;
   return 0;
 }
@@ -1162,6 +1168,63 @@ static int csr_upload_impl(eigenex_context_t c, int64_t n_global, int64_t row_be
 int eigenex_csr_upload(eigenex_context_t c, int64_t n_global, int64_t row_begin, int64_t n_rows, const int32_t* rowptr,
                        const int32_t* col_global, const double* val, eigenex_csr_t* out) {
   return csr_upload_impl(c, n_global, row_begin, n_rows, rowptr, col_global, val, 1, -1, out);
+}
+
+// CSR already in device memory (e.g. a torch tensor's data_ptr()): device-to-device copy into the library's padded
+// arrays, validated on the device first (a bad index would otherwise fault the GPU).  Unsharded contexts only.
+int eigenex_csr_upload_device(eigenex_context_t c, int64_t n, const int32_t* rowptr_dev, const int32_t* col_dev,
+                              const double* val_dev, int is_complex, eigenex_csr_t* out) {
+  if (!c || !out || !rowptr_dev || n <= 0) return fail(EIGENEX_ERR_ARG, "eigenex_csr_upload_device: bad argument");
+  if (c->P != 1) return fail(EIGENEX_ERR_ARG, "eigenex_csr_upload_device needs an unsharded context (rows of other shards would need host-side planning)");
+  HIPCHK(hipSetDevice(c->device));
+  const int es = is_complex ? 2 : 1;
+  int32_t ends[2] = {0, 0};
+  HIPCHK(hipMemcpyAsync(&ends[0], rowptr_dev, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(&ends[1], rowptr_dev + n, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const int64_t nnz = ends[1];
+  if (ends[0] != 0 || nnz < 0 || nnz > (int64_t)2147483647 - 16384) return fail(EIGENEX_ERR_ARG, "rowptr must start at 0 and nnz must be < 2^31 - 16384");
+  if (nnz > 0 && (!col_dev || !val_dev)) return fail(EIGENEX_ERR_ARG, "col/val is NULL");
+  DeviceTemp<unsigned int> bad;
+  HIPCHK(bad.alloc(2));
+  HIPCHK(hipMemsetAsync(bad, 0, 2 * sizeof(unsigned int), c->stream));
+  launch_check_csr(c->stream, rowptr_dev, col_dev, n, nnz, n, bad);
+  unsigned int nbad[2] = {0, 0};
+  HIPCHK(hipMemcpyAsync(nbad, bad, sizeof(nbad), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (nbad[0]) return fail(EIGENEX_ERR_ARG, "row pointers are not non-decreasing within [0, nnz]");
+  if (nbad[1]) return fail(EIGENEX_ERR_ARG, "column index out of range");
+  auto* m = new eigenex_csr_s();
+  m->ctx = c;
+  m->n_global = n;
+  m->es = es;
+  m->sh.resize(1);
+  CsrShard& s = m->sh[0];
+  s.gshard = c->local.front();
+  s.es = es;
+  s.rb = 0, s.re = n, s.nloc = n, s.npad = pad_rows(n), s.nnz = nnz;
+  int rc = [&]() -> int {
+    HIPCHK(hipMalloc(&s.rowptr, sizeof(int32_t) * (n + 1)));
+    HIPCHK(hipMalloc(&s.col, sizeof(int32_t) * (nnz + 8)));
+    HIPCHK(hipMalloc(&s.val, sizeof(double) * (nnz + 8) * es));
+    HIPCHK(hipMemsetAsync(s.col + nnz, 0, sizeof(int32_t) * 8, c->stream));
+    HIPCHK(hipMemsetAsync(s.val + nnz * es, 0, sizeof(double) * 8 * es, c->stream));
+    HIPCHK(hipMemcpyAsync(s.rowptr, rowptr_dev, sizeof(int32_t) * (n + 1), hipMemcpyDeviceToDevice, c->stream));
+    if (nnz) {
+      HIPCHK(hipMemcpyAsync(s.col, col_dev, sizeof(int32_t) * nnz, hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(hipMemcpyAsync(s.val, val_dev, sizeof(double) * nnz * es, hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+  }();
+  if (rc) {
+    std::string keep = g_err;
+    eigenex_csr_destroy(m);
+    g_err = keep;
+    return rc;
+  }
+  *out = m;
+  return 0;
 }
 
 int eigenex_csr_upload_ex(eigenex_context_t c, int64_t n_global, int64_t row_begin, int64_t n_rows, const int32_t* rowptr,

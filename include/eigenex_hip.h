@@ -163,6 +163,11 @@ int eigenex_block_upload(eigenex_context_t ctx, int64_t n_global, int n_row_sect
 int eigenex_block_upload_z(eigenex_context_t ctx, int64_t n_global, int n_row_sectors, const int64_t* row_sizes,
                            int n_col_sectors, const int64_t* col_sizes, int64_t nblocks, const int64_t* qr,
                            const int64_t* qc, const double* const* blocks_interleaved, eigenex_csr_t* out);
+/* CSR that already lives in device memory of this context's GPU (e.g. tensors of a GPU framework: pass their
+ * data pointers): copied device-to-device, never through the host, after a device-side check of the row pointers
+ * and column indices.  Unsharded contexts only; rowptr_dev[0] = 0; columns are global = local indices. */
+int eigenex_csr_upload_device(eigenex_context_t ctx, int64_t n, const int32_t* rowptr_dev, const int32_t* col_dev,
+                              const double* val_dev, int is_complex, eigenex_csr_t* out);
 /* passes of the (largest) local shard: 1 = not column-blocked */
 int eigenex_csr_column_blocks(eigenex_csr_t csr, int* passes);
 /* synthetic 7-point Laplacian on an n^3 grid generated on the device (BASELINE configs 2 and 4) */

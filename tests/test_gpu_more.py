@@ -304,3 +304,53 @@ def test_complex_block_operator(mods, shards):
     np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=0, atol=1e-12)
     np.testing.assert_allclose(outs[0][2], outs[1][2], rtol=0, atol=1e-12)
     ctx.close()
+
+
+def test_operator_from_device_memory(mods):
+    """eigenex_csr_upload_device: a CSR that lives in GPU memory (torch tensors here) becomes an operator without a
+    trip through the host; results identical to the host upload; malformed input is rejected on the device side
+    instead of faulting the GPU."""
+    capi, solver = mods
+    import torch
+
+    rng = np.random.default_rng(31)
+    n = 5000
+    rowptr, col, val = _random_csr(rng, n, 9)
+    x = rng.standard_normal(n)
+    dev = torch.device("cuda", 0)
+    t_rp, t_col, t_val = (torch.from_numpy(a).to(dev) for a in (rowptr, col, val))
+    ctx = capi.Context()
+    A_dev = capi.Csr.from_device(ctx, n, t_rp.data_ptr(), t_col.data_ptr(), t_val.data_ptr())
+    A_host = capi.Csr.upload(ctx, n, rowptr, col, val)
+    assert A_dev.info() == A_host.info()
+    ys = []
+    for A in (A_dev, A_host):
+        b = capi.Basis(ctx, A, n, 2)
+        b.upload(capi.VEC_W, x)
+        b.apply(capi.VEC_W, capi.VEC_V, 0.0)
+        ys.append(b.download(capi.VEC_V))
+        b.close()
+    np.testing.assert_array_equal(ys[0], ys[1])
+    np.testing.assert_array_equal(ys[0], cref.csr_spmv(rowptr, col, val, x))
+    # complex values
+    zval = val + 1j * rng.uniform(-1, 1, val.size)
+    t_z = torch.from_numpy(zval).to(dev)
+    Az = capi.Csr.from_device(ctx, n, t_rp.data_ptr(), t_col.data_ptr(), t_z.data_ptr(), is_complex=True)
+    bz = capi.Basis(ctx, Az, n, 2, dtype=np.complex128)
+    bz.upload(capi.VEC_W, x.astype(np.complex128))
+    bz.apply(capi.VEC_W, capi.VEC_V, 0.0)
+    np.testing.assert_allclose(bz.download(capi.VEC_V), ko.csr_matmul(rowptr, col, zval)(x.astype(np.complex128)), rtol=0, atol=1e-12)
+    bz.close()
+    # malformed inputs
+    bad_col = t_col.clone()
+    bad_col[17] = n
+    with pytest.raises(capi.EigenexError, match="column index out of range"):
+        capi.Csr.from_device(ctx, n, t_rp.data_ptr(), bad_col.data_ptr(), t_val.data_ptr())
+    bad_rp = t_rp.clone()
+    bad_rp[100] = bad_rp[101] + 1
+    with pytest.raises(capi.EigenexError, match="row pointers"):
+        capi.Csr.from_device(ctx, n, bad_rp.data_ptr(), t_col.data_ptr(), t_val.data_ptr())
+    with pytest.raises(capi.EigenexError, match="unsharded"):
+        c3 = capi.Context(loopback_shards=3)
+        capi.Csr.from_device(c3, n, t_rp.data_ptr(), t_col.data_ptr(), t_val.data_ptr())
+    ctx.close()
