@@ -65,6 +65,7 @@ void set_common(Solver& es, const std::string& k, double v) {
   else if (k == "computeEigenvectorsOn") es.setComputeEigenvectorsOn(v != 0.0);
   else if (k == "reserveSize") es.setReserveSize((Index)v);
   else if (k == "threshold") es.setThreshold(v);
+  else if (k == "speculativeLookahead") es.setSpeculativeLookahead(v != 0.0);
   else if (k == "orthogonalization") es.setOrthogonalization(v != 0.0 ? Orthogonalization::Sequential : Orthogonalization::Batched);
   else throw LanczosException("unknown setting: " + k);
 }

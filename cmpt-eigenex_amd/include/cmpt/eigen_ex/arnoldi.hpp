@@ -197,9 +197,14 @@ class ArnoldiBase {
     if (matrixHeight_ <= 0) return false;
     if (!hasOperator()) return false;
     if (nvec_ > 0 && callsRevealed_ == callsEnqueued_ && arnoldiStepIsUtmost()) return false;
-    if (callsRevealed_ == callsEnqueued_) enqueue_(1);
+    if (callsRevealed_ == callsEnqueued_) enqueue_(speculativeCalls_());
     return reveal_();
   }
+
+  // Extension: speculative lookahead, see LanczosBase::setSpeculationBound
+  void setSpeculationBound(Index bound) { speculationBound_ = bound; }
+  void setSpeculativeLookahead(bool on) { speculationOn_ = on; }
+  bool speculativeLookahead() const { return speculationOn_; }
 
   // Extension: see LanczosBase::prefetchLanczosSteps
   void prefetchArnoldiSteps(Index ncalls) {
@@ -279,8 +284,15 @@ class ArnoldiBase {
     }
   }
 
+  Index speculativeCalls_() const {
+    if (!speculationOn_ || !deviceOperator_ || speculationBound_ <= 1 || secondsPerCall_ <= 0.0) return 1;
+    const Index limit = secondsPerCall_ >= 2.0e-3 ? 1 : secondsPerCall_ >= 5.0e-4 ? 2 : secondsPerCall_ >= 1.0e-4 ? 4 : 8;
+    return std::max<Index>(1, std::min<Index>(limit, std::min<Index>(speculationBound_, matrixHeight_ - callsEnqueued_)));
+  }
+
   void enqueue_(Index ncalls) {
     if (ncalls <= 0) return;
+    const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     ensureDevice_(std::min<Index>(callsEnqueued_ + ncalls, matrixHeight_));
     if (!started_) {
       setInitialArnoldivector();
@@ -298,6 +310,8 @@ class ArnoldiBase {
     device::check(eigenex_arnoldi_state(dev_.handle(), &st, reinterpret_cast<double*>(devH_.data()), static_cast<int>(devLdh_)), "eigenex_arnoldi_state");
     devCallsTrue_ = st.calls_true;
     devResidue_ = st.residue;
+    const double per = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / static_cast<double>(ncalls);
+    if (secondsPerCall_ <= 0.0 || per < secondsPerCall_) secondsPerCall_ = per;
   }
 
   bool reveal_() {
@@ -346,6 +360,9 @@ class ArnoldiBase {
   bool devCreated_ = false;
   bool started_ = false;
   Index callsEnqueued_ = 0, callsRevealed_ = 0, devCallsTrue_ = 0;
+  bool speculationOn_ = true;
+  Index speculationBound_ = 1;
+  double secondsPerCall_ = 0.0;
   std::vector<Scalar> devH_;
   Index devLdh_ = 0;
   double devResidue_ = 0.0;
@@ -445,6 +462,10 @@ class ArnoldiEigenSolver {
   }
   ArnoldiEigenSolver& setDeviceContext(const std::shared_ptr<device::Context>& ctx) {
     arnoldiBase_.setDeviceContext(ctx);
+    return *this;
+  }
+  ArnoldiEigenSolver& setSpeculativeLookahead(bool on) {
+    arnoldiBase_.setSpeculativeLookahead(on);
     return *this;
   }
   ArnoldiEigenSolver& setOrthogonalization(Orthogonalization o) {
@@ -617,6 +638,7 @@ class ArnoldiEigenSolver {
           break;
         }
       }
+      arnoldiBase_.setSpeculationBound(maxIterations_ == unlimited ? std::numeric_limits<Index>::max() : maxIterations_ - arnoldiBase_.iterations());
       arnoldiBase_.updateArnoldiSteps();
       if (arnoldiBase_.arnoldivectorsSize() == 0) initialVectorFailed = true;
       solveHessenberg_(false);

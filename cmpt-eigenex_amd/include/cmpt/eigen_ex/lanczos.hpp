@@ -21,7 +21,9 @@
 #pragma once
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <limits>
 #include <complex>
 #include <functional>
 #include <map>
@@ -360,9 +362,19 @@ class LanczosBase {
   bool updateLanczosSteps() {
     if (matrixHeight_ <= 0) return false;
     if (!hasOperator()) return false;
-    if (callsRevealed_ == callsEnqueued_) enqueue_(1);
+    if (callsRevealed_ == callsEnqueued_) enqueue_(speculativeCalls_());
     return reveal_();
   }
+
+  // Extension: speculative lookahead.  When a step is asked for that has not been computed yet, up to `bound` calls
+  // are enqueued at once (never more than the adaptive limit below) and revealed one by one; a caller that stops
+  // early simply never looks at the surplus (iterations(), alpha(), lanczosvectors() only show revealed steps, and
+  // continueToCompute() picks the surplus up).  Hides the per-step host round trip of tolerance-driven runs on
+  // small systems; the limit shrinks with the measured time per step so that the work thrown away stays below
+  // roughly half a millisecond.  Device operators only: a host callback would observe the extra invocations.
+  void setSpeculationBound(Index bound) { speculationBound_ = bound; }
+  void setSpeculativeLookahead(bool on) { speculationOn_ = on; }
+  bool speculativeLookahead() const { return speculationOn_; }
 
   // Extension: run `ncalls` calls of updateLanczosSteps() on the GPU back to back with a
   // single host synchronisation; the following `ncalls` updateLanczosSteps() calls only
@@ -449,8 +461,15 @@ class LanczosBase {
     }
   }
 
+  Index speculativeCalls_() const {
+    if (!speculationOn_ || !deviceOperator_ || speculationBound_ <= 1 || secondsPerCall_ <= 0.0) return 1;
+    const Index limit = secondsPerCall_ >= 2.0e-3 ? 1 : secondsPerCall_ >= 5.0e-4 ? 2 : secondsPerCall_ >= 1.0e-4 ? 4 : 8;
+    return std::max<Index>(1, std::min<Index>(limit, std::min<Index>(speculationBound_, matrixHeight_ - callsEnqueued_)));
+  }
+
   void enqueue_(Index ncalls) {
     if (ncalls <= 0) return;
+    const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     // every successful call adds one vector
     ensureDevice_(callsEnqueued_ + ncalls);
     if (!started_) {
@@ -470,6 +489,8 @@ class LanczosBase {
     devAlpha_.resize(static_cast<std::size_t>(st.nalpha));
     devBeta_.resize(static_cast<std::size_t>(st.nbeta));
     devCallsTrue_ = st.calls_true;
+    const double per = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / static_cast<double>(ncalls);
+    if (secondsPerCall_ <= 0.0 || per < secondsPerCall_) secondsPerCall_ = per;  // the best batch is the least disturbed one
   }
 
   bool reveal_() {
@@ -523,6 +544,9 @@ class LanczosBase {
   Index callsEnqueued_ = 0, callsRevealed_ = 0, devCallsTrue_ = 0;
   std::vector<double> devAlpha_, devBeta_;
   bool stopApplied_ = false;
+  bool speculationOn_ = true;
+  Index speculationBound_ = 1;
+  double secondsPerCall_ = 0.0;
 };
 
 // ---------------------------------------------------------------------------
@@ -617,6 +641,11 @@ class LanczosEigenSolver {
   }
   LanczosEigenSolver& setDeviceContext(const std::shared_ptr<device::Context>& ctx) {
     lanczosBase_.setDeviceContext(ctx);
+    return *this;
+  }
+  // Extension: see LanczosBase::setSpeculationBound (default on; results do not depend on it)
+  LanczosEigenSolver& setSpeculativeLookahead(bool on) {
+    lanczosBase_.setSpeculativeLookahead(on);
     return *this;
   }
   LanczosEigenSolver& setOrthogonalization(Orthogonalization o) {
@@ -790,6 +819,9 @@ class LanczosEigenSolver {
           break;
         }
       }
+      // steps that may still run: the exit tests above can fire after any one of them, so anything beyond the next
+      // step is speculation (LanczosBase::setSpeculationBound)
+      lanczosBase_.setSpeculationBound(maxIterations_ == unlimited ? std::numeric_limits<Index>::max() : maxIterations_ - lanczosBase_.iterations());
       const bool stepped = lanczosBase_.updateLanczosSteps();
       if (lanczosBase_.lanczosvectorsSize() == 0) initialVectorFailed = true;
       if (!stepped && !initialVectorFailed && !lanczosBase_.lanczosStepIsUtmost()) {

@@ -354,3 +354,49 @@ def test_operator_from_device_memory(mods):
         c3 = capi.Context(loopback_shards=3)
         capi.Csr.from_device(c3, n, t_rp.data_ptr(), t_col.data_ptr(), t_val.data_ptr())
     ctx.close()
+
+
+@pytest.mark.parametrize("kind", ["lanczos", "arnoldi"])
+def test_speculative_lookahead_changes_nothing_but_time(mods, kind):
+    """Tolerance-driven runs on a device operator enqueue a few steps ahead of the exit tests (speculative
+    lookahead); everything observable -- iterations, subspace size, coefficients, eigenvalues, log -- must equal the
+    step-by-step run, and continueToCompute() must pick up the surplus steps."""
+    capi, solver = mods
+    import time
+
+    n = 24
+    N = n ** 3
+    ctx = capi.Context()
+    rng = np.random.default_rng(17)
+    init = rng.standard_normal(N)
+    out, times = [], []
+    for spec in (1, 0):
+        if kind == "lanczos":
+            es = solver.LanczosEigenSolver()
+            es.setDeviceOperator(capi.Csr.laplacian3d(ctx, n)).set(tolerance=1e-9, maxIterations=400, initialVector=init,
+                                                                  computeEigenvectorsOn=0, speculativeLookahead=spec)
+        else:
+            es = solver.ArnoldiEigenSolver()
+            es.setDeviceOperator(capi.Csr.laplacian3d(ctx, n)).set(tolerance=1e-7, maxIterations=150, initialVector=init,
+                                                                  computeEigenvectorsOn=0, speculativeLookahead=spec)
+        es.compute()  # warm-up: allocation, first-touch
+        t0 = time.perf_counter()
+        es.compute()
+        times.append(time.perf_counter() - t0)
+        r = es.results()
+        log = es.log()
+        # (continueToCompute logs the current Ritz value a second time, so the convergence test would fire at once:
+        # force the extra steps with minIterations, as in the reference)
+        es.set(minIterations=r["iterations"] + 7, maxIterations=r["iterations"] + 7).continueToCompute()
+        r2 = es.results()
+        out.append((r, log, r2))
+    (a, la, a2), (b, lb, b2) = out
+    assert la == lb and a["iterations"] == b["iterations"] and a["nvec"] == b["nvec"] and a["iterations"] > 20
+    np.testing.assert_array_equal(a["eigenvalues"], b["eigenvalues"])
+    assert a2["iterations"] == b2["iterations"] == a["iterations"] + 7
+    np.testing.assert_array_equal(a2["eigenvalues"], b2["eigenvalues"])
+    if kind == "lanczos":
+        np.testing.assert_array_equal(a["alpha"], b["alpha"])
+        np.testing.assert_array_equal(a2["beta"], b2["beta"])
+    print(f"{kind}: {a['iterations']} iterations, speculative {times[0]*1e3:.2f} ms, step by step {times[1]*1e3:.2f} ms")
+    ctx.close()
