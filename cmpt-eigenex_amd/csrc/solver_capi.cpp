@@ -193,6 +193,16 @@ int ar_set(void* p, const char* key, double v, double v_im) {
   });
 }
 
+// convergence log of index `index`: (re, im) pairs; returns the number of entries
+template <class S>
+int64_t ar_convergence_log(void* p, int64_t index, double* out, int64_t cap) {
+  auto& cl = static_cast<Box<ArnoldiEigenSolver<S>>*>(p)->es.convergenceLog();
+  auto it = cl.find((Index)index);
+  if (it == cl.end()) return 0;
+  for (int64_t i = 0; i < (int64_t)it->second.size() && i < cap; ++i) out[2 * i] = it->second[(size_t)i].real(), out[2 * i + 1] = it->second[(size_t)i].imag();
+  return (int64_t)it->second.size();
+}
+
 // sizes: [iterations, nvec, hess_rows, neigenvalues, eigvec_rows, eigvec_cols, nlog, info, hasWARN, hasERROR]
 template <class S>
 int ar_sizes(void* p, int64_t* out) {
@@ -496,7 +506,8 @@ int eigenex_solver_hessenberg_eigen(int n, const double* H_interleaved, double* 
   EIGENEX_SOLVER_COMMON(PFX, ArnoldiEigenSolver<S>)                                                                     \
   int PFX##set(void* p, const char* key, double v, double v_im) { return ar_set<S>(p, key, v, v_im); }                  \
   int PFX##sizes(void* p, int64_t* out) { return ar_sizes<S>(p, out); }                                                 \
-  int PFX##get(void* p, double* H, double* ev, double* X, double* res) { return ar_get<S>(p, H, ev, X, res); }
+  int PFX##get(void* p, double* H, double* ev, double* X, double* res) { return ar_get<S>(p, H, ev, X, res); }              \
+  int64_t PFX##convergence_log(void* p, int64_t i, double* out, int64_t cap) { return ar_convergence_log<S>(p, i, out, cap); }
 
 #define EIGENEX_TRLANCZOS_FAMILY(PFX, S)                                                                                \
   void* PFX##create(void) {                                                                                             \

@@ -86,6 +86,8 @@ def lib():
                                                 _dp, C.c_int64, _dp, C.c_double, C.c_int64, C.c_int]
         for kind in ("arnoldi", "zarnoldi"):
             getattr(L, f"eigenex_{kind}_solver_get").argtypes = [_vp, _dp, _dp, _dp, _dp]
+            getattr(L, f"eigenex_{kind}_solver_convergence_log").argtypes = [_vp, C.c_int64, _dp, C.c_int64]
+            getattr(L, f"eigenex_{kind}_solver_convergence_log").restype = C.c_int64
         _LIB = L
     return _LIB
 
@@ -372,6 +374,11 @@ class ArnoldiEigenSolver(_SolverBase):
         out = np.zeros(len(self._names), np.int64)
         _chk(self._f("sizes")(self.h, out.ctypes.data_as(_lp)))
         return dict(zip(self._names, (int(x) for x in out)))
+
+    def convergenceLog(self, index: int):
+        buf = np.zeros(1 << 16, np.complex128)
+        n = self._f("convergence_log")(self.h, index, _d(buf), buf.size)
+        return buf[:n].copy()
 
     def results(self):
         s = self._sizes()

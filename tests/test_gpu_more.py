@@ -400,3 +400,44 @@ def test_speculative_lookahead_changes_nothing_but_time(mods, kind):
         np.testing.assert_array_equal(a2["beta"], b2["beta"])
     print(f"{kind}: {a['iterations']} iterations, speculative {times[0]*1e3:.2f} ms, step by step {times[1]*1e3:.2f} ms")
     ctx.close()
+
+
+def test_arnoldi_deferred_convergence_log_matches_oracle(mods):
+    """With minIterations > 1 the per-iteration Hessenberg eigen-solves that no exit test can read are deferred until
+    convergenceLog() is looked at (the H_j are nested); the log must still equal the oracle's, entry by entry, for
+    the deferred part, the tested part and after continueToCompute()."""
+    capi, solver = mods
+    rng = np.random.default_rng(23)
+    N = 600
+    rowptr, col, val = _random_csr(rng, N, 7)
+    matmul = ko.csr_matmul(rowptr, col, val)
+    init = rng.standard_normal(N)
+    ctx = capi.Context()
+    kw = dict(min_iterations=30, max_iterations=60, tolerance=1e-6)
+    ref = ko.ArnoldiEigenSolverOracle()
+    ref.set_matrix_multiplication(matmul, N)
+    ref.base.initial_vector = init.copy()
+    ref.indices_for_convergence = [0, -1, 2]
+    for k, v in kw.items():
+        setattr(ref, k, v)
+    ref.compute()
+    es = solver.ArnoldiEigenSolver()
+    es.setDeviceOperator(capi.Csr.upload(ctx, N, rowptr, col, val)).set(minIterations=30, maxIterations=60, tolerance=1e-6,
+                                                                          initialVector=init, indicesForConvergence=[0, -1, 2],
+                                                                          computeEigenvectorsOn=0)
+    es.compute()
+    r = es.results()
+    assert r["iterations"] == ref.base.iterations and es.log() == ref.log
+    scale = max(abs(np.asarray(ref.eigenvalues)))
+    for idx in (0, -1, 2):
+        got, want = es.convergenceLog(idx), np.asarray(ref.convergence_log[idx])
+        assert got.size == want.size >= 30
+        # |lambda| ties (conjugate pairs) may be ordered either way: compare up to conjugation
+        assert np.all(np.minimum(abs(got - want), abs(got - want.conj())) <= 1e-9 * scale), idx
+    ref.min_iterations = ref.max_iterations = ref.base.iterations + 5
+    ref.continue_to_compute()
+    es.set(minIterations=r["iterations"] + 5, maxIterations=r["iterations"] + 5).continueToCompute()
+    got, want = es.convergenceLog(0), np.asarray(ref.convergence_log[0])
+    assert got.size == want.size
+    assert np.all(np.minimum(abs(got - want), abs(got - want.conj())) <= 1e-9 * scale)
+    ctx.close()
