@@ -155,6 +155,10 @@ def test_config2_laplacian_fixed_iterations(mods, mode):
     cl = es.convergenceLog(0)
     assert cl.size == m + 1
     assert abs(cl[-1] - th_ref[0]) < 1e-10
+    # every entry (those below minIterations - 1 are diagonalised lazily, on this access): lowest Ritz value of T_j
+    want = [ko.tridiagonal_eigh(c.alpha[: j + 1], c.beta[:j], vectors=False)[0][0] for j in range(m + 1)]
+    np.testing.assert_allclose(cl, want, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(es.convergenceLog(0), cl, rtol=0, atol=0)
     ctx.close()
 
 
