@@ -376,20 +376,18 @@ __device__ __forceinline__ double2 nt_ld_d2(const double* p) {
   return make_double2(v.x, v.y);
 }
 
-// Tile schedule of a persistent SpMV workgroup.  Plain: tiles b, b+G, ...  XCD-aware (T1 of the CDNA
-// guide): workgroups b and b+8 share an XCD (round-robin dispatch), so XCD x = b%8 walks its own
-// contiguous eighth of the tiles with its G/8 workgroups; neighbouring rows' operator-input lines are
-// then fetched into one L2 instead of eight.  Placement only changes speed, never results.
+// Tile schedule of a persistent SpMV workgroup.  Plain: tiles b, b+G, ...: the grid advances over the rows as one
+// frontier of G tiles per step.  XCD-sliced (flag bit 0): workgroups b and b+8 share an XCD (round-robin
+// dispatch), so within every frontier step XCD x = b%8 takes the contiguous eighth [x*G/8, (x+1)*G/8) of the
+// step's tiles: neighbouring rows' operator-input lines are then fetched into one L2 instead of eight, and the
+// frontier stays single (splitting the whole row range into eight far-apart chunks, tried first, cost 7 %).
+// Placement only changes speed, never results.
 struct TileRange {
   int64_t first, step, end;
 };
-__device__ __forceinline__ TileRange spmv_tiles(int64_t ntiles, int xcd_contiguous) {
+__device__ __forceinline__ TileRange spmv_tiles(int64_t ntiles, int xcd_sliced) {
   const int64_t G = gridDim.x, b = blockIdx.x;
-  if (xcd_contiguous && (G & 7) == 0) {
-    const int64_t chunk = (ntiles + 7) >> 3, x = b & 7, j = b >> 3;
-    const int64_t lo = x * chunk, hi = lo + chunk < ntiles ? lo + chunk : ntiles;
-    return TileRange{lo + j, G >> 3, hi};
-  }
+  if (xcd_sliced && (G & 7) == 0) return TileRange{(b & 7) * (G >> 3) + (b >> 3), G, ntiles};
   return TileRange{b, G, ntiles};
 }
 

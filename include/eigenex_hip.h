@@ -200,7 +200,9 @@ int eigenex_basis_reserve(eigenex_basis_t b, int capacity);
 int eigenex_basis_capacity(eigenex_basis_t b, int* capacity);
 /* tuning knobs: workgroups per CU of the persistent grids (slab kernels dots/update, SpMV; 1..16, defaults 2 and 4)
  * and `flags`, a bit set (default 0):
- *   bit 0  XCD-contiguous tile order of the SpMV (measured 7 % slower on the 512^3 stencil)
+ *   bit 0  XCD-sliced tile order of the SpMV: within each step of the row frontier every XCD takes a contiguous eighth
+ *          of the tiles (measured: no change on the 7-point stencil, -0.2 %..+0.6 %; cutting the whole row range into
+ *          eight chunks, the first attempt, was 7 % slower)
  *   bit 1  non-temporal loads of the CSR value/column streams (+5 % on a random 32-per-row CSR, slower on stencils)
  * Results do not depend on the knobs beyond the summation order of the per-workgroup partial sums. */
 int eigenex_basis_tune(eigenex_basis_t b, int vec_blocks_per_cu, int spmv_blocks_per_cu, int flags);
