@@ -19,6 +19,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libeigenex_hip.so")
 ORTHO_BATCHED = 0
 ORTHO_SEQUENTIAL = 1
 ORTHO_BATCHED_TWICE = 2
+ORTHO_BATCHED_ADAPTIVE = 3
 VEC_V = -1
 VEC_W = -2
 VEC_START = -3

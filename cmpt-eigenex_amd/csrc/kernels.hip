@@ -492,7 +492,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int32_t* __restrict__ row
       if (shift != 0.0) yr = add_product_nofma(yr, shift, xr);  // lanczos.hpp:390-392
       y[r] = yr;
       if (u_out) u_out[r] = xr;
-      dot = fma(xr, yr, dot);
+      dot = (pass & kPassSelfNorm) ? fma(yr, yr, dot) : fma(xr, yr, dot);
     }
     rs = nrs, re = nre, p0 = np0, p1 = np1;
   }
@@ -584,8 +584,12 @@ __global__ __launch_bounds__(kBlock) void k_spmv_z(const int32_t* __restrict__ r
       }
       y[r] = yr;
       if (u_out) u_out[r] = xr;
-      dr = fma(xr.x, yr.x, fma(xr.y, yr.y, dr));   // conj(u) * y
-      di = fma(xr.x, yr.y, fma(-xr.y, yr.x, di));
+      if (pass & kPassSelfNorm) {
+        dr = fma(yr.x, yr.x, fma(yr.y, yr.y, dr));  // |y|^2
+      } else {
+        dr = fma(xr.x, yr.x, fma(xr.y, yr.y, dr));   // conj(u) * y
+        di = fma(xr.x, yr.y, fma(-xr.y, yr.x, di));
+      }
     }
   }
   if (partials) {
@@ -610,7 +614,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_z(const int32_t* __restrict__ r
 __global__ __launch_bounds__(kBlock) void k_block_spmv(BlockOperatorView op, const double* __restrict__ x_ext,
                                                             const double* __restrict__ scale_ptr, double shift,
                                                             double* __restrict__ y, double* __restrict__ u_out, int64_t n,
-                                                            int64_t ntiles, double* __restrict__ partials,
+                                                            int64_t ntiles, double* __restrict__ partials, int pass,
                                                             const Ctrl* __restrict__ ctrl) {
   __shared__ double lds4[4];
   if (ctrl->stopped) return;
@@ -642,7 +646,7 @@ __global__ __launch_bounds__(kBlock) void k_block_spmv(BlockOperatorView op, con
     if (shift != 0.0) yr = add_product_nofma(yr, shift, xr);  // lanczos.hpp:390-392
     y[r] = yr;
     if (u_out) u_out[r] = xr;
-    dot = fma(xr, yr, dot);
+    dot = (pass & kPassSelfNorm) ? fma(yr, yr, dot) : fma(xr, yr, dot);
   }
   if (partials) {
     dot = block_sum(dot, lds4);
@@ -656,7 +660,7 @@ __global__ __launch_bounds__(kBlock) void k_block_spmv_z(BlockOperatorView op, c
                                                          const double* __restrict__ scale_ptr, double shift_re,
                                                          double shift_im, double2* __restrict__ y,
                                                          double2* __restrict__ u_out, int64_t n, int64_t ntiles,
-                                                         double* __restrict__ partials, int pstride,
+                                                         double* __restrict__ partials, int pstride, int pass,
                                                          const Ctrl* __restrict__ ctrl) {
   __shared__ double lds4[4];
   if (ctrl->stopped) return;
@@ -709,8 +713,12 @@ __global__ __launch_bounds__(kBlock) void k_block_spmv_z(BlockOperatorView op, c
     }
     y[r] = yr;
     if (u_out) u_out[r] = xr;
-    dr = fma(xr.x, yr.x, fma(xr.y, yr.y, dr));  // conj(u) * y
-    di = fma(xr.x, yr.y, fma(-xr.y, yr.x, di));
+    if (pass & kPassSelfNorm) {
+      dr = fma(yr.x, yr.x, fma(yr.y, yr.y, dr));  // |y|^2
+    } else {
+      dr = fma(xr.x, yr.x, fma(xr.y, yr.y, dr));  // conj(u) * y
+      di = fma(xr.x, yr.y, fma(-xr.y, yr.x, di));
+    }
   }
   if (partials) {
     dr = block_sum(dr, lds4);
@@ -849,6 +857,20 @@ __global__ void k_arnoldi_end(Ctrl* ctrl, const double* h, double* H, int ldh, i
     ctrl->iterations++;
     ctrl->calls_true++;
   }
+}
+
+// Adaptive second Gram-Schmidt pass (Daniel-Gragg-Kaufman-Stewart): the first pass has cancelled too much of the
+// vector when ||w_after||^2 < eta^2 ||w_before||^2 (eta = 1/sqrt 2).  pass2 is a second control block whose
+// `stopped` flag the second-pass kernels obey: they run only when the criterion asks for them.
+__global__ void k_decide_second_pass(const Ctrl* ctrl, Ctrl* pass2, const double* nrm2_before, const double* nrm2_after, double eta2) {
+  if (threadIdx.x != 0) return;
+  const bool again = !ctrl->stopped && (*nrm2_after < eta2 * *nrm2_before);
+  pass2->stopped = again ? 0 : 1;
+}
+// nrm2_final = the second pass's norm if it ran, else the first pass's
+__global__ void k_select_norm(const Ctrl* pass2, const double* nrm2_first, const double* nrm2_second, double* nrm2_final) {
+  if (threadIdx.x != 0) return;
+  *nrm2_final = pass2->stopped ? *nrm2_first : *nrm2_second;
 }
 
 // dst[i] += src[i] (coefficients of a second Gram-Schmidt pass folded into the first)
@@ -1147,17 +1169,17 @@ void launch_spmv(hipStream_t s, const int32_t* rowptr, const int32_t* col, const
 }
 
 void launch_block_spmv(hipStream_t s, const BlockOperatorView& op, const double* x_ext, const double* scale, double shift,
-                       double* y, double* u_out, int64_t n, double* partials, int grid, const Ctrl* ctrl) {
+                       double* y, double* u_out, int64_t n, double* partials, int grid, const Ctrl* ctrl, int pass) {
   hipLaunchKernelGGL(k_block_spmv, dim3(grid), dim3(kBlock), 0, s, op, x_ext, scale, shift, y, u_out, n,
-                     (n + kBlock - 1) / kBlock, partials, ctrl);
+                     (n + kBlock - 1) / kBlock, partials, pass, ctrl);
 }
 
 void launch_block_spmv_z(hipStream_t s, const BlockOperatorView& op, const double* x_ext, const double* scale, double shift_re,
                          double shift_im, double* y, double* u_out, int64_t n, double* partials, int pstride, int grid,
-                         const Ctrl* ctrl) {
+                         const Ctrl* ctrl, int pass) {
   hipLaunchKernelGGL(k_block_spmv_z, dim3(grid), dim3(kBlock), 0, s, op, reinterpret_cast<const double2*>(x_ext), scale, shift_re,
                      shift_im, reinterpret_cast<double2*>(y), reinterpret_cast<double2*>(u_out), n, (n + kBlock - 1) / kBlock, partials,
-                     pstride, ctrl);
+                     pstride, pass, ctrl);
 }
 
 void launch_scale(hipStream_t s, const double* x, const double* scale_dev, double scale_host, double* out, int64_t n,
@@ -1198,6 +1220,13 @@ void launch_arnoldi_begin(hipStream_t s, Ctrl* ctrl, double threshold, int64_t n
 
 void launch_arnoldi_end(hipStream_t s, Ctrl* ctrl, const double* h, double* H, int ldh, int es) {
   hipLaunchKernelGGL(k_arnoldi_end, dim3(1), dim3(kBlock), 0, s, ctrl, h, H, ldh, es);
+}
+
+void launch_decide_second_pass(hipStream_t s, const Ctrl* ctrl, Ctrl* pass2, const double* nrm2_before, const double* nrm2_after, double eta2) {
+  hipLaunchKernelGGL(k_decide_second_pass, dim3(1), dim3(64), 0, s, ctrl, pass2, nrm2_before, nrm2_after, eta2);
+}
+void launch_select_norm(hipStream_t s, const Ctrl* pass2, const double* nrm2_first, const double* nrm2_second, double* nrm2_final) {
+  hipLaunchKernelGGL(k_select_norm, dim3(1), dim3(64), 0, s, pass2, nrm2_first, nrm2_second, nrm2_final);
 }
 
 void launch_add_small(hipStream_t s, double* dst, const double* src, int n, const Ctrl* ctrl) {

@@ -65,7 +65,8 @@ void launch_reduce(hipStream_t s, const double* partials, int pstride, int nbloc
 // y = A*(x*scale) + shift*(x*scale); u_out = x*scale (optional); partials[block] = partial (x*scale).y (optional)
 // Column-blocked operators run one launch per pass: `pass` bit 0 (kPassCarry) = the row sums start from y (left by
 // the previous pass), bit 1 (kPassNotLast) = store the raw row sums only (no shift, u_out, dot).
-enum { kPassCarry = 1, kPassNotLast = 2 };
+// bit 2 (kPassSelfNorm): the partials hold ||y||^2 instead of (x*scale).y (adaptive Gram-Schmidt of the Arnoldi step)
+enum { kPassCarry = 1, kPassNotLast = 2, kPassSelfNorm = 4 };
 void launch_spmv(hipStream_t s, const int32_t* rowptr, const int32_t* col, const double* val, const double* x_ext,
                  const double* scale, double shift, double* y, double* u_out, int64_t n, double* partials, int grid,
                  const Ctrl* ctrl, int spmv_flags = 0, int pass = 0);
@@ -85,11 +86,11 @@ struct BlockOperatorView {
   const int32_t* rowgrp;
 };
 void launch_block_spmv(hipStream_t s, const BlockOperatorView& op, const double* x_ext, const double* scale, double shift,
-                       double* y, double* u_out, int64_t n, double* partials, int grid, const Ctrl* ctrl);
+                       double* y, double* u_out, int64_t n, double* partials, int grid, const Ctrl* ctrl, int pass = 0);
 // complex blocks: bval holds (re, im) pairs, gent counts entries; x/y/u_out interleaved; partials as launch_spmv_z
 void launch_block_spmv_z(hipStream_t s, const BlockOperatorView& op, const double* x_ext, const double* scale, double shift_re,
                          double shift_im, double* y, double* u_out, int64_t n, double* partials, int pstride, int grid,
-                         const Ctrl* ctrl);
+                         const Ctrl* ctrl, int pass = 0);
 // host-operator path: u_out = x*scale
 void launch_scale(hipStream_t s, const double* x, const double* scale_dev, double scale_host, double* out, int64_t n,
                   const Ctrl* ctrl);
@@ -120,6 +121,9 @@ void launch_arnoldi_begin(hipStream_t s, Ctrl* ctrl, double threshold, int64_t n
 // Arnoldi end of a call: H[0..k][k] = h[0..k], H[k+1][k] = 0, ++iterations
 void launch_arnoldi_end(hipStream_t s, Ctrl* ctrl, const double* h, double* H, int ldh, int es);
 void launch_add_small(hipStream_t s, double* dst, const double* src, int n, const Ctrl* ctrl);
+// adaptive second Gram-Schmidt pass: pass2->stopped = !(nrm2_after < eta2*nrm2_before) (or ctrl stopped)
+void launch_decide_second_pass(hipStream_t s, const Ctrl* ctrl, Ctrl* pass2, const double* nrm2_before, const double* nrm2_after, double eta2);
+void launch_select_norm(hipStream_t s, const Ctrl* pass2, const double* nrm2_first, const double* nrm2_second, double* nrm2_final);
 void launch_restart_fix(hipStream_t s, Ctrl* ctrl, double* alpha, double* beta, int m, int nkeep, double coupling_last);
 // vector accepted into the basis: ++nvec  (after the operator has been applied with `scale`)
 void launch_accept_vector(hipStream_t s, Ctrl* ctrl);

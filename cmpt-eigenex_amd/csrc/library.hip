@@ -212,6 +212,7 @@ struct BasisShard {
   double* X = nullptr;  // Ritz vector scratch (ldv x 8), lazy
   Ctrl* ctrl = nullptr;
   Ctrl* ctrl_zero = nullptr;  // always-zero control block for the stand-alone primitives
+  Ctrl* ctrl_pass2 = nullptr; // obeyed by the kernels of an adaptive second Gram-Schmidt pass
   int g_vec = 1, g_spmv = 1, pstride = 1, spmv_flags = 0;  // XCD-contiguous SpMV tiles measured 7 % slower at 512^3
 };
 
@@ -236,6 +237,9 @@ struct eigenex_basis_s {
   // offsets (in doubles) into hbuf behind the es*maxcols coefficient entries
   int slot_nrm() const { return es * maxcols; }
   int slot_alpha() const { return es * maxcols + 1; }  // (re, im) for complex
+  int slot_nrm_before() const { return es * maxcols + 3; }  // adaptive Gram-Schmidt: ||v||^2 before, after pass 1, after pass 2
+  int slot_nrm_first() const { return es * maxcols + 6; }
+  int slot_nrm_second() const { return es * maxcols + 7; }
   int slot_a() const { return es * maxcols + 4; }
   int slot_b() const { return es * maxcols + 5; }
   int base_h2() const { return es * maxcols + 8; }  // coefficients of the second Gram-Schmidt pass
@@ -678,17 +682,21 @@ ColumnSet colset(BasisShard& s, int first, int stride, int count, int qfirst, in
 
 // ---- enqueue helpers (all local shards, then the collective) -----------------
 // h[slot .. slot+ncols) = all-reduced dots of w0(src, tt) with the column set
+// use_ctrl: 0 = the always-zero control block (stand-alone primitives), 1 = the state's control block,
+// 2 = the second-pass control block of the adaptive Gram-Schmidt
+inline const Ctrl* pick_ctrl(const BasisShard& s, int use_ctrl) { return use_ctrl == 2 ? s.ctrl_pass2 : use_ctrl ? s.ctrl : s.ctrl_zero; }
+
 int enq_dots(eigenex_basis_s* b, int src_ref, bool three_term, int k, int first, int stride, int count, int qfirst,
-             int nq, int slot, bool use_ctrl, int base = 0) {
+             int nq, int slot, int use_ctrl, int base = 0) {
   eigenex_context_s* c = b->ctx;
   const int ncols = count + nq;
   if (ncols <= 0) return 0;
   for (auto& s : b->sh) {
     ThreeTerm tt{nullptr, nullptr, nullptr, nullptr};
     if (three_term) tt = ThreeTerm{s.V + (int64_t)k * s.ldd, k > 0 ? s.V + (int64_t)(k - 1) * s.ldd : nullptr, s.alpha + k, s.beta + (k > 0 ? k - 1 : 0)};
-    const Ctrl* ctl = use_ctrl ? s.ctrl : s.ctrl_zero;
+    const Ctrl* ctl = pick_ctrl(s, use_ctrl);
     {
-      ProfScope ps(c, EIGENEX_K_DOTS, 8.0 * s.nd * ncols + 8.0 * s.nd);
+      ProfScope ps(c, EIGENEX_K_DOTS, use_ctrl == 2 ? 0.0 : 8.0 * s.nd * ncols + 8.0 * s.nd);  // a conditional pass books no bytes
       launch_dots(c->stream, vec_ptr(s, b->cap, b->nq, src_ref), tt, colset(s, first, stride, count, qfirst, nq), s.nd,
                   s.partials, s.pstride, s.g_vec, ctl, b->es == 2);
     }
@@ -700,25 +708,26 @@ int enq_dots(eigenex_basis_s* b, int src_ref, bool three_term, int k, int first,
 
 // dst = w0(src, tt) - sum h[slot+c]*col_c ; hbuf[slot_nrm] = all-reduced ||dst||^2 (if want_norm)
 int enq_update(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_term, int k, int first, int stride, int count,
-               int qfirst, int nq, int slot, bool want_norm, bool use_ctrl, int base = 0) {
+               int qfirst, int nq, int slot, bool want_norm, int use_ctrl, int base = 0, int nrm_slot = -1) {
+  if (nrm_slot < 0) nrm_slot = b->slot_nrm();
   eigenex_context_s* c = b->ctx;
   const int ncols = count + nq;
   for (auto& s : b->sh) {
     ThreeTerm tt{nullptr, nullptr, nullptr, nullptr};
     if (three_term) tt = ThreeTerm{s.V + (int64_t)k * s.ldd, k > 0 ? s.V + (int64_t)(k - 1) * s.ldd : nullptr, s.alpha + k, s.beta + (k > 0 ? k - 1 : 0)};
-    const Ctrl* ctl = use_ctrl ? s.ctrl : s.ctrl_zero;
+    const Ctrl* ctl = pick_ctrl(s, use_ctrl);
     {
-      ProfScope ps(c, EIGENEX_K_UPDATE, 8.0 * s.nd * ncols + 24.0 * s.nd + (three_term ? 32.0 * s.nd : 0.0));
+      ProfScope ps(c, EIGENEX_K_UPDATE, use_ctrl == 2 ? 0.0 : 8.0 * s.nd * ncols + 24.0 * s.nd + (three_term ? 32.0 * s.nd : 0.0));
       launch_update(c->stream, vec_ptr(s, b->cap, b->nq, src_ref), vec_ptr(s, b->cap, b->nq, dst_ref), tt,
                     colset(s, first, stride, count, qfirst, nq), s.hbuf + base + slot * b->es, s.nd, s.partials, s.g_vec, ctl,
                     b->es == 2);
     }
     if (want_norm) {
       ProfScope ps(c, EIGENEX_K_SMALL, 0.0);
-      launch_reduce(c->stream, s.partials, s.pstride, s.g_vec, 1, s.hbuf + b->slot_nrm(), ctl);
+      launch_reduce(c->stream, s.partials, s.pstride, s.g_vec, 1, s.hbuf + nrm_slot, ctl);
     }
   }
-  return want_norm ? allreduce(b, b->slot_nrm(), 1) : 0;
+  return want_norm ? allreduce(b, nrm_slot, 1) : 0;
 }
 
 // Gram-Schmidt of the vector in src against the selected columns, result in dst,
@@ -726,10 +735,30 @@ int enq_update(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_term, in
 // Sequential: the reference's order, one vector at a time; q_first: orthogonalizing
 // vectors before the basis vectors (Arnoldi, arnoldi.hpp:373-383) or after (Lanczos,
 // lanczos.hpp:416-425).
+// norm_before: hbuf[slot_nrm_before] holds the all-reduced ||src||^2 (adaptive scheme only)
 int enq_orthogonalize(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_term, int k, int first, int stride,
-                      int count, int nq, bool q_first) {
-  if (b->ortho_mode == EIGENEX_ORTHO_BATCHED || b->ortho_mode == EIGENEX_ORTHO_BATCHED_TWICE) {
-    const bool twice = b->ortho_mode == EIGENEX_ORTHO_BATCHED_TWICE && count + nq > 0;
+                      int count, int nq, bool q_first, bool norm_before = false) {
+  int mode = b->ortho_mode;
+  if (mode == EIGENEX_ORTHO_BATCHED_ADAPTIVE && (three_term || count + nq == 0)) mode = EIGENEX_ORTHO_BATCHED;
+  if (mode == EIGENEX_ORTHO_BATCHED_ADAPTIVE && !norm_before) mode = EIGENEX_ORTHO_BATCHED_TWICE;
+  if (mode == EIGENEX_ORTHO_BATCHED_ADAPTIVE) {
+    hipStream_t st = b->ctx->stream;
+    CHK(enq_dots(b, src_ref, false, 0, first, stride, count, 0, nq, 0, 1));
+    CHK(enq_update(b, src_ref, dst_ref, false, 0, first, stride, count, 0, nq, 0, true, 1, 0, b->slot_nrm_first()));
+    for (auto& s : b->sh)
+      launch_decide_second_pass(st, s.ctrl, s.ctrl_pass2, s.hbuf + b->slot_nrm_before(), s.hbuf + b->slot_nrm_first(), 0.5);
+    // second pass: enqueued always, executed only when the criterion asked for it (its collectives run on stale
+    // data otherwise and their results are ignored)
+    CHK(enq_dots(b, dst_ref, false, 0, first, stride, count, 0, nq, 0, 2, b->base_h2()));
+    CHK(enq_update(b, dst_ref, dst_ref, false, 0, first, stride, count, 0, nq, 0, true, 2, b->base_h2(), b->slot_nrm_second()));
+    for (auto& s : b->sh) {
+      launch_add_small(st, s.hbuf, s.hbuf + b->base_h2(), (count + nq) * b->es, s.ctrl_pass2);
+      launch_select_norm(st, s.ctrl_pass2, s.hbuf + b->slot_nrm_first(), s.hbuf + b->slot_nrm_second(), s.hbuf + b->slot_nrm());
+    }
+    return 0;
+  }
+  if (mode == EIGENEX_ORTHO_BATCHED || mode == EIGENEX_ORTHO_BATCHED_TWICE) {
+    const bool twice = mode == EIGENEX_ORTHO_BATCHED_TWICE && count + nq > 0;
     CHK(enq_dots(b, src_ref, three_term, k, first, stride, count, 0, nq, 0, true));
     CHK(enq_update(b, src_ref, dst_ref, three_term, k, first, stride, count, 0, nq, 0, !twice, true));
     if (!twice) return 0;
@@ -766,18 +795,18 @@ int enq_orthogonalize(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_t
 // one operator application on one shard: a launch per column-block pass, the row sums carried in y
 void launch_operator(hipStream_t st, const CsrShard* m, int es, const double* x_ext, const double* scale, double shift,
                      double shift_im, double* y, double* u_out, double* partials, int pstride, int grid, const Ctrl* ctrl,
-                     int flags) {
+                     int flags, int last_pass_flags = 0) {
   if (m->blocked) {
     const BlockOperatorView op{m->bval, m->gent, m->gcol, m->cols, m->grow0, m->rowgrp};
     if (es == 2)
-      launch_block_spmv_z(st, op, x_ext, scale, shift, shift_im, y, u_out, m->nloc, partials, pstride, grid, ctrl);
+      launch_block_spmv_z(st, op, x_ext, scale, shift, shift_im, y, u_out, m->nloc, partials, pstride, grid, ctrl, last_pass_flags);
     else
-      launch_block_spmv(st, op, x_ext, scale, shift, y, u_out, m->nloc, partials, grid, ctrl);
+      launch_block_spmv(st, op, x_ext, scale, shift, y, u_out, m->nloc, partials, grid, ctrl, last_pass_flags);
     return;
   }
   for (int k = 0; k < m->passes; ++k) {
     const bool last = k == m->passes - 1;
-    const int pass = (k > 0 ? kPassCarry : 0) | (last ? 0 : kPassNotLast);
+    const int pass = (k > 0 ? kPassCarry : 0) | (last ? last_pass_flags : kPassNotLast);
     const int32_t* rp = m->rowptr + (int64_t)k * (m->nloc + 1);
     if (es == 2)
       launch_spmv_z(st, rp, m->col, m->val, x_ext, scale, shift, shift_im, y, u_out, m->nloc, last ? partials : nullptr, pstride,
@@ -790,12 +819,23 @@ void launch_operator(hipStream_t st, const CsrShard* m, int es, const double* x_
 
 // v = (A + shift) * (w*scale), basis column `ucol` = w*scale, optional alpha = u.v -> hbuf[slot_alpha]
 // Returns 1 in *skipped if the device had already stopped (host-operator path only).
-int enq_apply(eigenex_basis_s* b, int ucol, bool want_dot) {
+// self_norm (instead of want_dot, device operators only): hbuf[slot_nrm_before] = all-reduced ||v||^2
+int enq_apply(eigenex_basis_s* b, int ucol, bool want_dot, bool self_norm = false) {
   eigenex_context_s* c = b->ctx;
   if (b->csr) {
     CHK(halo_exchange(b));
     for (auto& s : b->sh) {
       CsrShard* m = s.csr;
+      if (self_norm) {
+        {
+          ProfScope ps(c, EIGENEX_K_SPMV, (m->blocked ? 8.0 * b->es * m->nnz + 4.0 * m->nstripcols + 4.0 * m->nloc : (4.0 + 8.0 * b->es) * m->nnz + 4.0 * (m->nloc + 1)) + 32.0 * s.nd);
+          launch_operator(c->stream, m, b->es, s.w, &s.ctrl->scale, b->shift, b->shift_im, s.v, s.V + (int64_t)ucol * s.ldd, s.partials,
+                          s.pstride, s.g_spmv, s.ctrl, s.spmv_flags, kPassSelfNorm);
+        }
+        ProfScope ps(c, EIGENEX_K_SMALL, 0.0);
+        launch_reduce(c->stream, s.partials, s.pstride, s.g_spmv, 1, s.hbuf + b->slot_nrm_before(), s.ctrl);
+        continue;
+      }
       {
         const double opbytes = m->blocked ? 8.0 * b->es * m->nnz + 4.0 * m->nstripcols + 4.0 * m->nloc : (4.0 + 8.0 * b->es) * m->nnz + 4.0 * (m->nloc + 1);
         ProfScope ps(c, EIGENEX_K_SPMV, opbytes + 32.0 * s.nd + (want_dot ? 16.0 * s.nd : 0.0));
@@ -807,6 +847,7 @@ int enq_apply(eigenex_basis_s* b, int ucol, bool want_dot) {
         launch_reduce(c->stream, s.partials, s.pstride, s.g_spmv, b->es, s.hbuf + b->slot_alpha(), s.ctrl);
       }
     }
+    if (self_norm) return allreduce(b, b->slot_nrm_before(), 1);
     return want_dot ? allreduce(b, b->slot_alpha(), b->es) : 0;
   }
   // operator lives in host code (MatMulFunction, lanczos.hpp:116): stage through pinned memory
@@ -884,10 +925,11 @@ int arnoldi_call(eigenex_basis_s* b) {
     for (auto& s : b->sh) launch_arnoldi_begin(st, s.ctrl, b->threshold, b->n_global, b->cap, s.H, b->ldh, b->es);  // :357-365
     if (k >= b->cap) return 0;  // full Krylov space: the begin kernel has recorded "returned false"
   }
-  CHK(enq_apply(b, k, false));  // :333-336, :369-372
+  const bool adaptive = b->ortho_mode == EIGENEX_ORTHO_BATCHED_ADAPTIVE && b->csr != nullptr;
+  CHK(enq_apply(b, k, false, adaptive));  // :333-336, :369-372
   if (!b->csr && b->shift != 0.0) { /* shift applied inside enq_apply's host path */ }
   // :337-345, :373-383
-  CHK(enq_orthogonalize(b, EIGENEX_VEC_V, EIGENEX_VEC_W, false, 0, 0, 1, k + 1, b->nq, true));
+  CHK(enq_orthogonalize(b, EIGENEX_VEC_V, EIGENEX_VEC_W, false, 0, 0, 1, k + 1, b->nq, true, adaptive));
   for (auto& s : b->sh) {
     launch_fin_norm(st, s.ctrl, s.hbuf + b->slot_nrm(), b->threshold, kFinArnoldi, s.beta);  // :348, :385
     launch_arnoldi_end(st, s.ctrl, s.hbuf, s.H, b->ldh, b->es);
@@ -1410,7 +1452,7 @@ int eigenex_basis_destroy(eigenex_basis_t b) {
   (void)hipStreamSynchronize(b->ctx->stream);
   for (auto& s : b->sh) {
     for (void* p : {(void*)s.V, (void*)s.Q, (void*)s.v, (void*)s.w, (void*)s.start, (void*)s.partials, (void*)s.hbuf, (void*)s.alpha,
-                    (void*)s.beta, (void*)s.H, (void*)s.X, (void*)s.ctrl, (void*)s.ctrl_zero})
+                    (void*)s.beta, (void*)s.H, (void*)s.X, (void*)s.ctrl, (void*)s.ctrl_zero, (void*)s.ctrl_pass2})
       if (p) (void)hipFree(p);
   }
   if (b->pin_in) (void)hipHostFree(b->pin_in);
@@ -1495,6 +1537,8 @@ int eigenex_basis_create_ex(eigenex_context_t c, eigenex_csr_t csr, int64_t n_gl
       HIPCHK(hipMalloc(&s.ctrl_zero, sizeof(Ctrl)));
       HIPCHK(hipMemsetAsync(s.ctrl, 0, sizeof(Ctrl), c->stream));
       HIPCHK(hipMemsetAsync(s.ctrl_zero, 0, sizeof(Ctrl), c->stream));
+      HIPCHK(hipMalloc(&s.ctrl_pass2, sizeof(Ctrl)));
+      HIPCHK(hipMemsetAsync(s.ctrl_pass2, 0, sizeof(Ctrl), c->stream));
     }
     if (std::getenv("EIGENEX_DEBUG_POINTERS"))  // allocation placement, for timing investigations
       for (auto& s : b->sh)
@@ -1588,7 +1632,7 @@ int eigenex_basis_configure(eigenex_basis_t b, double eigenvalue_shift, double t
 int eigenex_basis_configure_z(eigenex_basis_t b, double shift_re, double shift_im, double threshold, int64_t interval,
                               int ortho_mode) {
   if (!b) return fail(EIGENEX_ERR_ARG, "basis is NULL");
-  if (ortho_mode < EIGENEX_ORTHO_BATCHED || ortho_mode > EIGENEX_ORTHO_BATCHED_TWICE) return fail(EIGENEX_ERR_ARG, "bad ortho_mode");
+  if (ortho_mode < EIGENEX_ORTHO_BATCHED || ortho_mode > EIGENEX_ORTHO_BATCHED_ADAPTIVE) return fail(EIGENEX_ERR_ARG, "bad ortho_mode");
   if (shift_im != 0.0 && b->es != 2) return fail(EIGENEX_ERR_ARG, "a complex shift needs a complex basis");
   b->shift = shift_re;
   b->shift_im = shift_im;

@@ -66,7 +66,10 @@ void set_common(Solver& es, const std::string& k, double v) {
   else if (k == "reserveSize") es.setReserveSize((Index)v);
   else if (k == "threshold") es.setThreshold(v);
   else if (k == "speculativeLookahead") es.setSpeculativeLookahead(v != 0.0);
-  else if (k == "orthogonalization") es.setOrthogonalization(v != 0.0 ? Orthogonalization::Sequential : Orthogonalization::Batched);
+  else if (k == "orthogonalization") {  // 0 batched, 1 sequential (reference order), 2 batched twice, 3 batched adaptive
+    if (v < 0.0 || v > 3.0) throw LanczosException("orthogonalization must be 0..3");
+    es.setOrthogonalization(static_cast<Orthogonalization>(static_cast<int>(v)));
+  }
   else throw LanczosException("unknown setting: " + k);
 }
 

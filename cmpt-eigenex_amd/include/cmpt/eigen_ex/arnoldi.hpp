@@ -338,7 +338,10 @@ class ArnoldiBase {
   MatMulFunction matrixMultiplication_;
   std::shared_ptr<device::CsrOperator> deviceOperator_;
   std::shared_ptr<device::Context> context_;
-  Orthogonalization ortho_ = Orthogonalization::Batched;
+  // A q_k has O(1) components along the basis: one classical Gram-Schmidt pass is not enough once Ritz values have
+  // converged (include/eigenex_hip.h, EIGENEX_ORTHO_BATCHED_ADAPTIVE); the reference's modified Gram-Schmidt is
+  // Orthogonalization::Sequential
+  Orthogonalization ortho_ = Orthogonalization::BatchedAdaptive;
   Scalar eigenvalueShift_ = Scalar(0.0);
   Index matrixHeight_ = 0;
   VectorType initialVector_;

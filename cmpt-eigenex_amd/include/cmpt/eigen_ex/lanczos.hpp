@@ -52,8 +52,11 @@ class DefaultTolerance {
 enum ComputationInfo { Success = 0, NumericalIssue = 1, NoConvergence = 2, InvalidInput = 3 };
 
 enum class Orthogonalization {
-  Batched = EIGENEX_ORTHO_BATCHED,       // one dots pass + one update pass per step (default)
-  Sequential = EIGENEX_ORTHO_SEQUENTIAL  // the reference's strictly sequential modified Gram-Schmidt
+  Batched = EIGENEX_ORTHO_BATCHED,        // one dots pass + one update pass per step (Lanczos default)
+  Sequential = EIGENEX_ORTHO_SEQUENTIAL,  // the reference's strictly sequential modified Gram-Schmidt
+  BatchedTwice = EIGENEX_ORTHO_BATCHED_TWICE,       // the batched pass applied twice
+  BatchedAdaptive = EIGENEX_ORTHO_BATCHED_ADAPTIVE  // second pass only when the first cancelled too much, decided on
+                                                    // the device (Arnoldi default; see include/eigenex_hip.h)
 };
 
 namespace detail {

@@ -66,7 +66,16 @@ enum {
   EIGENEX_ORTHO_SEQUENTIAL = 1,
   /* batched Gram-Schmidt applied twice per step ("twice is enough"): for steps whose coefficients are
    * not small, e.g. the first step after a thick restart; doubles the traffic over the basis */
-  EIGENEX_ORTHO_BATCHED_TWICE = 2
+  EIGENEX_ORTHO_BATCHED_TWICE = 2,
+  /* batched Gram-Schmidt with a second pass only when the first one cancelled too much of the vector
+   * (||w_after|| < ||w_before|| / sqrt 2, Daniel-Gragg-Kaufman-Stewart), decided ON THE DEVICE: the second-pass
+   * kernels are always enqueued and return at once when not needed.  Meant for the Arnoldi step, whose vector
+   * A q_k has O(1) components along the basis: a single classical pass loses orthogonality completely once Ritz
+   * values converge (measured: |V^T V - I| = 1 on a 16^3 Laplacian at m = 150; the reference's modified
+   * Gram-Schmidt: 0.43; this scheme and BATCHED_TWICE: 3e-16).  Lanczos steps (the three-term recurrence has
+   * removed the large components already) treat it as BATCHED; where ||w_before|| is not at hand (host-callback
+   * operators, the start vector's deflation) it acts as BATCHED_TWICE. */
+  EIGENEX_ORTHO_BATCHED_ADAPTIVE = 3
 };
 
 /* vector references inside a basis (arguments named *_ref) */

@@ -626,3 +626,54 @@ def test_spmv_random_structures_bit_exact(capi, seed):
         b.close()
         A.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("shards", [1, 3])
+def test_arnoldi_orthogonality_when_ritz_values_converge(capi, shards):
+    """Arnoldi on a symmetric operator run far past the convergence of its extremal Ritz values: the Krylov basis is
+    then ill-conditioned.  The reference's single modified Gram-Schmidt pass (mode 1) loses orthogonality to O(0.1)
+    here; the adaptive scheme (mode 3, the solver classes' Arnoldi default: a second batched pass whenever the first
+    cancelled more than half of the vector, decided on the device) and mode 2 keep it at rounding level and the
+    largest Ritz value exact.  Adaptive == twice where a second pass is needed; on a benign operator it skips it."""
+    n, m = 16, 150
+    N = n ** 3
+    rowptr, col, val = cref.laplacian3d(n)
+    lam_max = 3 * (2 - 2 * np.cos(n * np.pi / (n + 1)))
+    init = np.random.default_rng(1).standard_normal(N)
+    ctx = capi.Context(loopback_shards=shards) if shards > 1 else capi.Context()
+    A = capi.Csr.upload(ctx, N, rowptr, col, val)
+    defect, H = {}, {}
+    for mode in (1, 2, 3):
+        b = capi.Basis(ctx, A, N, m)
+        b.configure(ortho_mode=mode)
+        b.upload(capi.VEC_W, init)
+        b.arnoldi_enqueue(m)
+        st, H[mode] = b.arnoldi_state()
+        assert st.nvec == m
+        idx = np.arange(0, m, 7)
+        G = np.stack([b.dots(capi.VEC_COL(int(c)), 0, 1, m) for c in idx])
+        G[np.arange(idx.size), idx] -= 1.0
+        defect[mode] = np.abs(G).max()
+        b.close()
+    assert defect[2] < 1e-13 and defect[3] < 1e-13
+    assert defect[1] > 1e-3  # the reference's scheme, for comparison
+    for mode in (2, 3):
+        ev = np.linalg.eigvals(H[mode][:m, :m])
+        assert abs(ev.real.max() - lam_max) < 1e-10 and np.abs(ev.imag).max() < 1e-8
+    np.testing.assert_allclose(H[3][:m, :m], H[2][:m, :m], rtol=0, atol=1e-10)
+    A.close()
+    # benign case: random non-symmetric matrix, m small -> the second pass is skipped: H equals the single-pass H bit for bit
+    rng = np.random.default_rng(5)
+    rp, cl, vl = _random_csr(rng, 3000, 9)
+    x0 = rng.standard_normal(3000)
+    B = capi.Csr.upload(ctx, 3000, rp, cl, vl)
+    Hs = []
+    for mode in (0, 3):
+        b = capi.Basis(ctx, B, 3000, 20)
+        b.configure(ortho_mode=mode)
+        b.upload(capi.VEC_W, x0)
+        b.arnoldi_enqueue(20)
+        Hs.append(b.arnoldi_state()[1])
+        b.close()
+    np.testing.assert_array_equal(Hs[0], Hs[1])
+    ctx.close()
