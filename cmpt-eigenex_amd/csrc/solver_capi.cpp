@@ -466,6 +466,16 @@ int eigenex_solver_hessenberg_eigen(int n, const double* H_interleaved, double* 
   });
 }
 
+// eigenvalues only of a REAL upper-Hessenberg matrix (column-major), Francis double-shift QR; values: (re, im) pairs
+int eigenex_solver_hessenberg_values_real(int n, const double* H, double* values) {
+  return guard([&] {
+    std::vector<double> A(H, H + (size_t)n * n);
+    std::vector<small_eigen::cplx> vals;
+    if (!small_eigen::hessenberg_real_values(A, n, vals)) throw LanczosException("QR iteration did not converge");
+    std::memcpy(values, vals.data(), sizeof(double) * 2 * (size_t)n);
+  });
+}
+
 #define EIGENEX_SOLVER_COMMON(PFX, SOLVER)                                                                              \
   void* PFX##create(void) {                                                                                             \
     try {                                                                                                               \

@@ -164,7 +164,7 @@ class ArnoldiBase {
     nvec_ = 0;
     h_.clear();
     vectorCache_.clear();
-    callsEnqueued_ = callsRevealed_ = 0;
+    callsEnqueued_ = callsFetched_ = callsRevealed_ = 0;
     devCallsTrue_ = 0;
     devH_.clear();
     started_ = false;
@@ -196,8 +196,8 @@ class ArnoldiBase {
   bool updateArnoldiSteps() {
     if (matrixHeight_ <= 0) return false;
     if (!hasOperator()) return false;
-    if (nvec_ > 0 && callsRevealed_ == callsEnqueued_ && arnoldiStepIsUtmost()) return false;
-    if (callsRevealed_ == callsEnqueued_) enqueue_(speculativeCalls_());
+    if (nvec_ > 0 && callsRevealed_ == callsFetched_ && arnoldiStepIsUtmost()) return false;
+    if (callsRevealed_ == callsFetched_) enqueue_(speculativeCalls_());
     return reveal_();
   }
 
@@ -209,7 +209,7 @@ class ArnoldiBase {
   // Extension: see LanczosBase::prefetchLanczosSteps
   void prefetchArnoldiSteps(Index ncalls) {
     if (matrixHeight_ <= 0 || !hasOperator()) return;
-    const Index pending = callsEnqueued_ - callsRevealed_;
+    const Index pending = callsFetched_ - callsRevealed_;
     if (ncalls > pending) enqueue_(ncalls - pending);
   }
   void reserveBasis(Index nvec) { capacityHint_ = nvec; }
@@ -284,15 +284,17 @@ class ArnoldiBase {
     }
   }
 
+  // adaptive limit of steps computed beyond the one asked for (see LanczosBase::setSpeculationBound)
+  Index lookaheadLimit_() const {
+    if (!speculationOn_ || !deviceOperator_ || secondsPerCall_ <= 0.0) return 1;
+    return secondsPerCall_ >= 2.0e-3 ? 1 : secondsPerCall_ >= 5.0e-4 ? 2 : secondsPerCall_ >= 1.0e-4 ? 4 : 8;
+  }
   Index speculativeCalls_() const {
-    if (!speculationOn_ || !deviceOperator_ || speculationBound_ <= 1 || secondsPerCall_ <= 0.0) return 1;
-    const Index limit = secondsPerCall_ >= 2.0e-3 ? 1 : secondsPerCall_ >= 5.0e-4 ? 2 : secondsPerCall_ >= 1.0e-4 ? 4 : 8;
-    return std::max<Index>(1, std::min<Index>(limit, std::min<Index>(speculationBound_, matrixHeight_ - callsEnqueued_)));
+    return std::max<Index>(1, std::min<Index>(lookaheadLimit_(), std::min<Index>(speculationBound_, matrixHeight_ - callsEnqueued_)));
   }
 
-  void enqueue_(Index ncalls) {
-    if (ncalls <= 0) return;
-    const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  // hand `ncalls` more step calls to the device; does not wait
+  void submit_(Index ncalls) {
     ensureDevice_(std::min<Index>(callsEnqueued_ + ncalls, matrixHeight_));
     if (!started_) {
       setInitialArnoldivector();
@@ -304,14 +306,33 @@ class ArnoldiBase {
     }
     device::check(eigenex_arnoldi_enqueue(dev_.handle(), static_cast<int>(ncalls)), "eigenex_arnoldi_enqueue");
     callsEnqueued_ += ncalls;
+  }
+
+  // wait for everything submitted and take over the Hessenberg matrix and the counters
+  void fetch_() {
     eigenex_state_t st;
     devLdh_ = dev_.capacity() + 2;
     devH_.assign(static_cast<std::size_t>(devLdh_) * static_cast<std::size_t>(dev_.capacity() + 1), Scalar(0.0));
     device::check(eigenex_arnoldi_state(dev_.handle(), &st, reinterpret_cast<double*>(devH_.data()), static_cast<int>(devLdh_)), "eigenex_arnoldi_state");
     devCallsTrue_ = st.calls_true;
     devResidue_ = st.residue;
-    const double per = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / static_cast<double>(ncalls);
-    if (secondsPerCall_ <= 0.0 || per < secondsPerCall_) secondsPerCall_ = per;
+    callsFetched_ = callsEnqueued_;
+  }
+
+  // see LanczosBase::enqueue_: blocking for `ncalls`, then the next batch is put in flight
+  void enqueue_(Index ncalls) {
+    if (ncalls <= 0) return;
+    const Index inFlight = callsEnqueued_ - callsFetched_;
+    const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    if (ncalls > inFlight) submit_(ncalls - inFlight);
+    const Index fetchedNow = callsEnqueued_ - callsFetched_;
+    fetch_();
+    if (inFlight == 0) {
+      const double per = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / static_cast<double>(fetchedNow);
+      if (secondsPerCall_ <= 0.0 || per < secondsPerCall_) secondsPerCall_ = per;
+    }
+    const Index ahead = std::min<Index>(lookaheadLimit_(), std::min<Index>(speculationBound_ - fetchedNow, matrixHeight_ - callsEnqueued_));
+    if (lookaheadLimit_() > 1 && ahead > 0 && devCallsTrue_ == callsFetched_) submit_(ahead);
   }
 
   bool reveal_() {
@@ -362,7 +383,7 @@ class ArnoldiBase {
   bool initialDirty_ = true;
   bool devCreated_ = false;
   bool started_ = false;
-  Index callsEnqueued_ = 0, callsRevealed_ = 0, devCallsTrue_ = 0;
+  Index callsEnqueued_ = 0, callsFetched_ = 0, callsRevealed_ = 0, devCallsTrue_ = 0;  // submitted >= fetched >= revealed
   bool speculationOn_ = true;
   Index speculationBound_ = 1;
   double secondsPerCall_ = 0.0;
@@ -591,10 +612,15 @@ class ArnoldiEigenSolver {
       eigenvectors_h_.resize(0, 0);
       return;
     }
-    std::vector<small_eigen::cplx> H(static_cast<std::size_t>(n) * n), vals, vecs;
-    for (int c = 0; c < n; ++c)
-      for (int r = 0; r < n; ++r) H[static_cast<std::size_t>(r) + static_cast<std::size_t>(c) * n] = hessenbergMatrix_(r, c);
-    small_eigen::hessenberg(H, n, vals, wantVectors ? &vecs : nullptr);
+    std::vector<small_eigen::cplx> vals, vecs;
+    if (!wantVectors && !detail::IsComplex<Scalar>::value) {
+      valuesOfRealHessenberg_(hessenbergMatrix_, n, vals);  // real operator, eigenvalues only: double-shift QR in real arithmetic
+    } else {
+      std::vector<small_eigen::cplx> H(static_cast<std::size_t>(n) * n);
+      for (int c = 0; c < n; ++c)
+        for (int r = 0; r < n; ++r) H[static_cast<std::size_t>(r) + static_cast<std::size_t>(c) * n] = hessenbergMatrix_(r, c);
+      small_eigen::hessenberg(H, n, vals, wantVectors ? &vecs : nullptr);
+    }
     std::vector<std::size_t> order(static_cast<std::size_t>(n));
     std::iota(order.begin(), order.end(), std::size_t(0));
     std::stable_sort(order.begin(), order.end(), [&vals](std::size_t a, std::size_t b) { return std::abs(vals[a]) > std::abs(vals[b]); });
@@ -695,14 +721,27 @@ class ArnoldiEigenSolver {
     }
   }
 
+  // eigenvalues of the leading n x n block of a Hessenberg matrix with real entries
+  static void valuesOfRealHessenberg_(const MatrixType& Hm, int n, std::vector<small_eigen::cplx>& vals) {
+    std::vector<double> H(static_cast<std::size_t>(n) * n);
+    for (int c = 0; c < n; ++c)
+      for (int r = 0; r < n; ++r) H[static_cast<std::size_t>(r) + static_cast<std::size_t>(c) * n] = std::real(Hm(r, c));
+    small_eigen::hessenberg_real_values(H, n, vals);
+  }
+
   // Ritz values of the leading j x j block of the current Hessenberg matrix, descending modulus
   std::vector<ComplexScalar> ritzValuesOfLeadingBlock_(Index j) const {
     const MatrixType Hfull = arnoldiBase_.makeHessenbergMatrix();
     const int n = static_cast<int>(j);
-    std::vector<small_eigen::cplx> H(static_cast<std::size_t>(n) * n), vals;
-    for (int c = 0; c < n; ++c)
-      for (int r = 0; r < n; ++r) H[static_cast<std::size_t>(r) + static_cast<std::size_t>(c) * n] = Hfull(r, c);
-    small_eigen::hessenberg(H, n, vals, nullptr);
+    std::vector<small_eigen::cplx> vals;
+    if (!detail::IsComplex<Scalar>::value) {
+      valuesOfRealHessenberg_(Hfull, n, vals);
+    } else {
+      std::vector<small_eigen::cplx> H(static_cast<std::size_t>(n) * n);
+      for (int c = 0; c < n; ++c)
+        for (int r = 0; r < n; ++r) H[static_cast<std::size_t>(r) + static_cast<std::size_t>(c) * n] = Hfull(r, c);
+      small_eigen::hessenberg(H, n, vals, nullptr);
+    }
     std::stable_sort(vals.begin(), vals.end(), [](const small_eigen::cplx& a, const small_eigen::cplx& b) { return std::abs(a) > std::abs(b); });
     return std::vector<ComplexScalar>(vals.begin(), vals.end());
   }

@@ -328,7 +328,7 @@ class LanczosBase {
     alpha_.clear();
     beta_.clear();
     vectorCache_.clear();
-    callsEnqueued_ = callsRevealed_ = 0;
+    callsEnqueued_ = callsFetched_ = callsRevealed_ = 0;
     devCallsTrue_ = 0;
     devAlpha_.clear();
     devBeta_.clear();
@@ -365,7 +365,7 @@ class LanczosBase {
   bool updateLanczosSteps() {
     if (matrixHeight_ <= 0) return false;
     if (!hasOperator()) return false;
-    if (callsRevealed_ == callsEnqueued_) enqueue_(speculativeCalls_());
+    if (callsRevealed_ == callsFetched_) enqueue_(speculativeCalls_());
     return reveal_();
   }
 
@@ -384,7 +384,7 @@ class LanczosBase {
   // reveal their results.  Identical results, no per-step round trip.
   void prefetchLanczosSteps(Index ncalls) {
     if (matrixHeight_ <= 0 || !hasOperator()) return;
-    const Index pending = callsEnqueued_ - callsRevealed_;
+    const Index pending = callsFetched_ - callsRevealed_;
     if (ncalls > pending) enqueue_(ncalls - pending);
   }
 
@@ -464,15 +464,17 @@ class LanczosBase {
     }
   }
 
+  // adaptive limit of steps computed beyond the one asked for (see setSpeculationBound)
+  Index lookaheadLimit_() const {
+    if (!speculationOn_ || !deviceOperator_ || secondsPerCall_ <= 0.0) return 1;
+    return secondsPerCall_ >= 2.0e-3 ? 1 : secondsPerCall_ >= 5.0e-4 ? 2 : secondsPerCall_ >= 1.0e-4 ? 4 : 8;
+  }
   Index speculativeCalls_() const {
-    if (!speculationOn_ || !deviceOperator_ || speculationBound_ <= 1 || secondsPerCall_ <= 0.0) return 1;
-    const Index limit = secondsPerCall_ >= 2.0e-3 ? 1 : secondsPerCall_ >= 5.0e-4 ? 2 : secondsPerCall_ >= 1.0e-4 ? 4 : 8;
-    return std::max<Index>(1, std::min<Index>(limit, std::min<Index>(speculationBound_, matrixHeight_ - callsEnqueued_)));
+    return std::max<Index>(1, std::min<Index>(lookaheadLimit_(), std::min<Index>(speculationBound_, matrixHeight_ - callsEnqueued_)));
   }
 
-  void enqueue_(Index ncalls) {
-    if (ncalls <= 0) return;
-    const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  // hand `ncalls` more step calls to the device; does not wait
+  void submit_(Index ncalls) {
     // every successful call adds one vector
     ensureDevice_(callsEnqueued_ + ncalls);
     if (!started_) {
@@ -485,6 +487,10 @@ class LanczosBase {
     }
     device::check(eigenex_lanczos_enqueue(dev_.handle(), static_cast<int>(ncalls)), "eigenex_lanczos_enqueue");
     callsEnqueued_ += ncalls;
+  }
+
+  // wait for everything submitted and take over alpha/beta and the counters
+  void fetch_() {
     eigenex_state_t st;
     devAlpha_.resize(static_cast<std::size_t>(callsEnqueued_ + 2));
     devBeta_.resize(static_cast<std::size_t>(callsEnqueued_ + 2));
@@ -492,8 +498,24 @@ class LanczosBase {
     devAlpha_.resize(static_cast<std::size_t>(st.nalpha));
     devBeta_.resize(static_cast<std::size_t>(st.nbeta));
     devCallsTrue_ = st.calls_true;
-    const double per = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / static_cast<double>(ncalls);
-    if (secondsPerCall_ <= 0.0 || per < secondsPerCall_) secondsPerCall_ = per;  // the best batch is the least disturbed one
+    callsFetched_ = callsEnqueued_;
+  }
+
+  // make `ncalls` more calls available to reveal_() (blocking); with speculation on, the next batch is submitted
+  // right after the fetch, so that the device computes it while the host digests this one (exit tests, QL solves)
+  void enqueue_(Index ncalls) {
+    if (ncalls <= 0) return;
+    const Index inFlight = callsEnqueued_ - callsFetched_;
+    const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    if (ncalls > inFlight) submit_(ncalls - inFlight);
+    const Index fetchedNow = callsEnqueued_ - callsFetched_;
+    fetch_();
+    if (inFlight == 0) {  // a clean measurement: nothing had been running ahead
+      const double per = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / static_cast<double>(fetchedNow);
+      if (secondsPerCall_ <= 0.0 || per < secondsPerCall_) secondsPerCall_ = per;  // the best batch is the least disturbed one
+    }
+    const Index ahead = std::min<Index>(lookaheadLimit_(), std::min<Index>(speculationBound_ - fetchedNow, matrixHeight_ - callsEnqueued_));
+    if (lookaheadLimit_() > 1 && ahead > 0 && devCallsTrue_ == callsFetched_) submit_(ahead);
   }
 
   bool reveal_() {
@@ -544,7 +566,7 @@ class LanczosBase {
   bool initialDirty_ = true;
   bool devCreated_ = false;
   bool started_ = false;
-  Index callsEnqueued_ = 0, callsRevealed_ = 0, devCallsTrue_ = 0;
+  Index callsEnqueued_ = 0, callsFetched_ = 0, callsRevealed_ = 0, devCallsTrue_ = 0;  // submitted >= fetched >= revealed
   std::vector<double> devAlpha_, devBeta_;
   bool stopApplied_ = false;
   bool speculationOn_ = true;

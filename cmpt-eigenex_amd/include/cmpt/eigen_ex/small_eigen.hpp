@@ -301,6 +301,144 @@ inline bool hessenberg(std::vector<cplx>& H, int n, std::vector<cplx>& values, s
   return ok;
 }
 
+// Eigenvalues only of a REAL upper-Hessenberg matrix (column-major n x n, overwritten): Francis' implicit
+// double-shift QR with deflation, rotations confined to the active block (no Schur vectors) -- the classical
+// EISPACK hqr scheme, a quarter of the arithmetic of the complex single-shift iteration above.  Complex pairs
+// come out with the positive imaginary part first (the order LAPACK and Eigen's EigenSolver use).  This is what
+// the Arnoldi front-end needs after every step of a real operator (arnoldi.hpp:811).
+inline bool hessenberg_real_values(std::vector<double>& H, int n, std::vector<cplx>& values) {
+  values.assign(static_cast<std::size_t>(n), cplx(0.0));
+  if (n == 0) return true;
+  auto a = [&](int r, int c) -> double& { return H[static_cast<std::size_t>(r) + static_cast<std::size_t>(c) * n]; };
+  auto sign = [](double x, double y) { return y >= 0.0 ? std::abs(x) : -std::abs(x); };
+  double anorm = 0.0;
+  for (int i = 0; i < n; ++i)
+    for (int j = std::max(i - 1, 0); j < n; ++j) anorm += std::abs(a(i, j));
+  int nn = n - 1;
+  double t = 0.0, p = 0.0, q = 0.0, r = 0.0, s = 0.0, w, x, y, z;
+  bool ok = true;
+  while (nn >= 0) {
+    int its = 0, l;
+    do {
+      for (l = nn; l >= 1; --l) {  // a negligible sub-diagonal entry splits the problem
+        s = std::abs(a(l - 1, l - 1)) + std::abs(a(l, l));
+        if (s == 0.0) s = anorm;
+        if (std::abs(a(l, l - 1)) + s == s) {
+          a(l, l - 1) = 0.0;
+          break;
+        }
+      }
+      x = a(nn, nn);
+      if (l == nn) {  // one real root
+        values[static_cast<std::size_t>(nn)] = cplx(x + t, 0.0);
+        --nn;
+      } else {
+        y = a(nn - 1, nn - 1);
+        w = a(nn, nn - 1) * a(nn - 1, nn);
+        if (l == nn - 1) {  // a 2 x 2 block: two real roots or a complex pair
+          p = 0.5 * (y - x);
+          q = p * p + w;
+          z = std::sqrt(std::abs(q));
+          x += t;
+          if (q >= 0.0) {
+            z = p + sign(z, p);
+            double r0 = x + z, r1 = r0;
+            if (z != 0.0) r1 = x - w / z;
+            values[static_cast<std::size_t>(nn - 1)] = cplx(r0, 0.0);
+            values[static_cast<std::size_t>(nn)] = cplx(r1, 0.0);
+          } else {
+            values[static_cast<std::size_t>(nn - 1)] = cplx(x + p, z);
+            values[static_cast<std::size_t>(nn)] = cplx(x + p, -z);
+          }
+          nn -= 2;
+        } else {  // no root yet: one more double-shift sweep
+          if (its == 90) {
+            ok = false;  // give up on this block: report its diagonal
+            for (int i = l; i <= nn; ++i) values[static_cast<std::size_t>(i)] = cplx(a(i, i) + t, 0.0);
+            nn = l - 1;
+            break;
+          }
+          if (its == 10 || its == 20 || its == 40) {  // exceptional shift
+            t += x;
+            for (int i = 0; i <= nn; ++i) a(i, i) -= x;
+            s = std::abs(a(nn, nn - 1)) + std::abs(a(nn - 1, nn - 2));
+            y = x = 0.75 * s;
+            w = -0.4375 * s * s;
+          }
+          ++its;
+          int m;
+          for (m = nn - 2; m >= l; --m) {  // two consecutive small sub-diagonal entries let the sweep start at m
+            z = a(m, m);
+            r = x - z;
+            s = y - z;
+            p = (r * s - w) / a(m + 1, m) + a(m, m + 1);
+            q = a(m + 1, m + 1) - z - r - s;
+            r = a(m + 2, m + 1);
+            s = std::abs(p) + std::abs(q) + std::abs(r);
+            p /= s;
+            q /= s;
+            r /= s;
+            if (m == l) break;
+            const double u = std::abs(a(m, m - 1)) * (std::abs(q) + std::abs(r));
+            const double v = std::abs(p) * (std::abs(a(m - 1, m - 1)) + std::abs(z) + std::abs(a(m + 1, m + 1)));
+            if (u + v == v) break;
+          }
+          for (int i = m + 2; i <= nn; ++i) {
+            a(i, i - 2) = 0.0;
+            if (i != m + 2) a(i, i - 3) = 0.0;
+          }
+          for (int k = m; k <= nn - 1; ++k) {  // Householder reflections of order 3 chase the bulge down
+            if (k != m) {
+              p = a(k, k - 1);
+              q = a(k + 1, k - 1);
+              r = 0.0;
+              if (k != nn - 1) r = a(k + 2, k - 1);
+              if ((x = std::abs(p) + std::abs(q) + std::abs(r)) != 0.0) {
+                p /= x;
+                q /= x;
+                r /= x;
+              }
+            }
+            if ((s = sign(std::sqrt(p * p + q * q + r * r), p)) != 0.0) {
+              if (k == m) {
+                if (l != m) a(k, k - 1) = -a(k, k - 1);
+              } else {
+                a(k, k - 1) = -s * x;
+              }
+              p += s;
+              x = p / s;
+              y = q / s;
+              z = r / s;
+              q /= p;
+              r /= p;
+              for (int j = k; j <= nn; ++j) {  // rows k, k+1, k+2
+                p = a(k, j) + q * a(k + 1, j);
+                if (k != nn - 1) {
+                  p += r * a(k + 2, j);
+                  a(k + 2, j) -= p * z;
+                }
+                a(k + 1, j) -= p * y;
+                a(k, j) -= p * x;
+              }
+              const int mmin = nn < k + 3 ? nn : k + 3;
+              for (int i = l; i <= mmin; ++i) {  // columns k, k+1, k+2
+                p = x * a(i, k) + y * a(i, k + 1);
+                if (k != nn - 1) {
+                  p += z * a(i, k + 2);
+                  a(i, k + 2) -= p * r;
+                }
+                a(i, k + 1) -= p * q;
+                a(i, k) -= p;
+              }
+            }
+          }
+        }
+      }
+    } while (l < nn - 1);
+  }
+  return ok;
+}
+
 }  // namespace small_eigen
 }  // namespace EigenEx
 }  // namespace cmpt

@@ -39,6 +39,7 @@ def lib():
         L.eigenex_solver_tridiagonal_eigen.argtypes = [C.c_int, _dp, _dp, _dp, _dp]
         L.eigenex_solver_hessenberg_eigen.argtypes = [C.c_int, _dp, _dp, _dp]
         L.eigenex_solver_symmetric_eigen.argtypes = [C.c_int, _dp, _dp, _dp]
+        L.eigenex_solver_hessenberg_values_real.argtypes = [C.c_int, _dp, _dp]
         _ip32 = C.POINTER(C.c_int32)
         L.eigenex_solver_triplets_to_csr.argtypes = [C.c_int64, C.c_int64, _lp, _lp, _dp, C.c_int, _ip32, _ip32, _dp, _lp]
         L.eigenex_solver_gershgorin_range.argtypes = [C.c_int64, C.c_int64, _lp, _lp, _dp, C.c_int, _dp]
@@ -135,6 +136,15 @@ def hessenberg_eigen(H, vectors=True):
     vecs = np.empty((n, n), np.complex128, order="F") if vectors else None
     _chk(lib().eigenex_solver_hessenberg_eigen(n, _d(H), _d(vals), _d(vecs) if vectors else None))
     return vals, vecs
+
+
+def hessenberg_values_real(H):
+    """eigenvalues of a real upper-Hessenberg matrix (double-shift QR in real arithmetic)"""
+    H = np.asfortranarray(H, np.float64)
+    n = H.shape[0]
+    vals = np.empty(n, np.complex128)
+    _chk(lib().eigenex_solver_hessenberg_values_real(n, _d(H), _d(vals)))
+    return vals
 
 
 def symmetric_eigen(A):

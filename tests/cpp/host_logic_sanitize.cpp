@@ -88,6 +88,25 @@ int main() {
       EXPECT(worst < 1e-9);
     }
   }
+  // real double-shift QR against the complex routine (eigenvalue multisets), incl. reducible input
+  for (int n : {1, 2, 3, 6, 25, 60}) {
+    std::vector<double> Hr((size_t)n * n, 0.0);
+    for (int c = 0; c < n; ++c)
+      for (int r = 0; r <= std::min(c + 1, n - 1); ++r) Hr[(size_t)c * n + r] = u(rng);
+    if (n > 4) Hr[(size_t)(n / 2 - 1) * n + n / 2] = 0.0;
+    std::vector<small_eigen::cplx> Hc(Hr.begin(), Hr.end()), vr, vc;
+    std::vector<double> work = Hr;
+    EXPECT(small_eigen::hessenberg_real_values(work, n, vr));
+    EXPECT(small_eigen::hessenberg(Hc, n, vc, nullptr));
+    for (const auto& x : vr) {
+      double best = 1e300;
+      std::size_t at = 0;
+      for (std::size_t k = 0; k < vc.size(); ++k)
+        if (std::abs(x - vc[k]) < best) best = std::abs(x - vc[k]), at = k;
+      EXPECT(best < 1e-9);
+      vc.erase(vc.begin() + (std::ptrdiff_t)at);
+    }
+  }
   // COO ingestion: duplicates, cancelling entries, row windows, bad indices
   {
     const Index n = 23, cnt = 400;

@@ -135,6 +135,31 @@ def test_small_eigen_hessenberg_vs_lapack(built):
             np.testing.assert_allclose(np.linalg.norm(vecs, axis=0), 1.0, atol=1e-12)
 
 
+def test_small_eigen_real_hessenberg_values_vs_lapack(built):
+    """Francis double-shift QR in real arithmetic (what a real Arnoldi run calls after every step): eigenvalues as a
+    multiset against LAPACK, reducible and symmetric inputs, conjugate pairs with the positive imaginary part first."""
+    _, solver = built
+    rng = np.random.default_rng(2)
+    for n in (1, 2, 3, 4, 5, 8, 17, 40, 80):
+        for trial in range(8):
+            H = np.triu(rng.standard_normal((n, n)), -1)
+            if trial % 4 == 1 and n > 3:
+                H[n // 2, n // 2 - 1] = 0.0
+            if trial % 4 == 2:
+                H = np.triu((H + H.T) / 2, -1)
+            vals = solver.hessenberg_values_real(H)
+            ref = list(np.linalg.eigvals(H))
+            for v in vals:
+                k = int(np.argmin([abs(v - r) for r in ref]))
+                assert abs(v - ref.pop(k)) < 1e-9 * max(1.0, np.abs(H).max())
+            for i in range(n - 1):
+                if vals[i].imag != 0 and vals[i + 1] == np.conj(vals[i]) and (i == 0 or vals[i - 1] != np.conj(vals[i])):
+                    assert vals[i].imag > 0
+            # same eigenvalues as the complex single-shift routine
+            zc, _ = solver.hessenberg_eigen(H, vectors=False)
+            assert abs(np.sort_complex(np.round(zc, 8)) - np.sort_complex(np.round(vals, 8))).max() < 1e-6
+
+
 def test_default_start_vector_is_the_references(built):
     """lanczos.hpp:214-218: std::mt19937 default seed + std::normal_distribution, normalised."""
     _, solver = built
