@@ -165,6 +165,7 @@ class ArnoldiBase {
     h_.clear();
     vectorCache_.clear();
     callsEnqueued_ = callsFetched_ = callsRevealed_ = 0;
+    speculationBound_ = 1;
     devCallsTrue_ = 0;
     devH_.clear();
     started_ = false;
@@ -648,6 +649,7 @@ class ArnoldiEigenSolver {
     if (matrixHeight() <= 0 || !arnoldiBase_.hasOperator()) info_ = InvalidInput;
     if (maxIterations_ != unlimited) arnoldiBase_.reserveBasis(maxIterations_);  // m iterations -> m vectors
     if (arnoldiBase_.arnoldivectorsSize() > 0) solveHessenberg_(false);
+    arnoldiBase_.setSpeculationBound(1);  // the certain calls are not speculation, and nothing may run beyond them yet
     arnoldiBase_.prefetchArnoldiSteps(certainCalls_());
     bool initialVectorFailed = false;
     while (true) {

@@ -330,6 +330,7 @@ class LanczosBase {
     vectorCache_.clear();
     callsEnqueued_ = callsFetched_ = callsRevealed_ = 0;
     devCallsTrue_ = 0;
+    speculationBound_ = 1;
     devAlpha_.clear();
     devBeta_.clear();
     stopApplied_ = false;
@@ -828,6 +829,7 @@ class LanczosEigenSolver {
     triValues_.clear();
     solveTridiagonal_();
     if (maxIterations_ != unlimited) lanczosBase_.reserveBasis(maxIterations_ + 1);  // m iterations -> m+1 vectors
+    lanczosBase_.setSpeculationBound(1);  // the certain calls are not speculation, and nothing may run beyond them yet
     lanczosBase_.prefetchLanczosSteps(certainCalls_());
     bool initialVectorFailed = false;
     while (true) {
