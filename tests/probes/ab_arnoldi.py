@@ -1,4 +1,4 @@
-"""In-process A/B of SpMV knobs on BASELINE config 3 (random CSR, N rows, 32/row): usage python scripts/ab_arnoldi.py N m rounds "vec,spmv,flags;..." [column_blocks] """
+"""In-process A/B of SpMV knobs on BASELINE config 3 (random CSR, N rows, 32/row): usage python tests/probes/ab_arnoldi.py N m rounds "vec,spmv,flags;..." [column_blocks] """
 import sys, time
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np

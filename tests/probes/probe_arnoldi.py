@@ -1,5 +1,5 @@
 """Device probe: Arnoldi m steps on a random CSR (N rows, 32 distinct columns/row), per-kernel HIP-event times.
-usage: python scripts/probe_arnoldi.py N m"""
+usage: python tests/probes/probe_arnoldi.py N m"""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np

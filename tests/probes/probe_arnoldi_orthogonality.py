@@ -1,7 +1,7 @@
 """Loss of orthogonality of the Arnoldi basis under the three Gram-Schmidt schemes (0 batched = classical GS in one
 pass, 1 sequential = the reference's modified GS, 2 batched twice, 3 batched adaptive) on operators whose Krylov basis becomes
 ill-conditioned (extremal eigenvalues converge): max |V^T V - I| and the error of the converged Ritz values.
-usage: python scripts/probe_arnoldi_orthogonality.py"""
+usage: python tests/probes/probe_arnoldi_orthogonality.py"""
 import sys
 sys.path.insert(0, ".")
 import numpy as np

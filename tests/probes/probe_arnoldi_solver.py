@@ -1,6 +1,6 @@
 """BASELINE config 3 through the solver class (ArnoldiEigenSolver<double>::compute, min = max = m), next to the
 bare step enqueue of the C ABI: shows the host share (Hessenberg eigenvalues per iteration for the convergence log).
-usage: python scripts/probe_arnoldi_solver.py [N=1000000] [m=80]"""
+usage: python tests/probes/probe_arnoldi_solver.py [N=1000000] [m=80]"""
 import sys, time
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np

@@ -1,7 +1,7 @@
 """Feasibility probe for a column-blocked SpMV on BASELINE config 3 (random CSR, N=1M, 32/row): time the
 operator as it is, then as K sub-operators holding only the columns of one block each (each block's slice
 of the input vector fits one XCD's L2).  Sum of the K pass times ~ blocked SpMV time (minus the y carry).
-usage: python scripts/probe_colblock.py N K"""
+usage: python tests/probes/probe_colblock.py N K"""
 import sys, time
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np

@@ -1,6 +1,6 @@
 """Throughput of the complex fp64 path: Hermitian 3-D hopping operator with Peierls phases on an n^3 grid
 (7 stored entries per interior row, complex values), Lanczos m steps with full re-orthogonalisation.
-usage: python scripts/probe_complex.py n m [rounds]"""
+usage: python tests/probes/probe_complex.py n m [rounds]"""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np
