@@ -84,8 +84,12 @@ def main():
 
     if not torch.cuda.is_available() or capi.device_count() < 1:
         sys.exit("bench.py needs an MI355X: the Krylov hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one GPU per rank; if the launcher narrowed the visible devices per rank (HIP_VISIBLE_DEVICES), local_rank may
+    # exceed what this process can see
+    ndev = capi.device_count()
+    dev_index = local_rank if local_rank < ndev else local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     rccl_id = None
     if world > 1:
@@ -104,7 +108,7 @@ def main():
 
     n, m = args.n, args.m
     N = n ** 3
-    ctx = capi.Context(device=local_rank, rank=rank, world_size=world, rccl_id=rccl_id)
+    ctx = capi.Context(device=dev_index, rank=rank, world_size=world, rccl_id=rccl_id)
     if world > 1 and not ctx.rccl_selftest():
         sys.exit(f"rank {rank}: RCCL self-test (all-reduce / all-gather / send-recv ring) returned wrong data")
     A = capi.Csr.laplacian3d(ctx, n)
