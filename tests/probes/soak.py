@@ -1,0 +1,60 @@
+"""Leak / stability soak: create and destroy contexts, operators (CSR, column-blocked, blocks, device-resident),
+bases and solvers of every kind many times; device memory must return to where it started.
+usage: python tests/probes/soak.py [rounds=40]"""
+import sys
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import numpy as np
+import torch
+from cmpt_eigenex_amd import capi, solver
+from oracle import cref
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(0)
+n = 20
+N = n ** 3
+rowptr, col, val = cref.laplacian3d(n)
+sizes = [int(v) for v in rng.integers(4, 30, 60)]
+blocks = {}
+for q in range(len(sizes)):
+    D = rng.standard_normal((sizes[q], sizes[q]))
+    blocks[(q, q)] = (D + D.T) / 2
+Nb = sum(sizes)
+torch.cuda.init()
+free0 = None
+for r in range(rounds):
+    shards = (1, 2, 3)[r % 3]
+    ctx = capi.Context(loopback_shards=shards) if shards > 1 else capi.Context()
+    A = capi.Csr.upload(ctx, N, rowptr, col, val, column_blocks=(None, 0, 3)[r % 3])
+    es = solver.LanczosEigenSolver()
+    es.setDeviceOperator(A).set(tolerance=1e-8, maxIterations=60, maxEigenvalues=3)
+    es.compute(); es.compute()
+    out = es.expWithLanczos(-0.3, N)
+    ar = solver.ArnoldiEigenSolver()
+    ar.setDeviceOperator(A).set(minIterations=20, maxIterations=20, maxEigenvalues=2)
+    ar.compute()
+    tr = solver.ThickRestartLanczosEigenSolver()
+    tr.setDeviceOperator(A).set(numberOfEigenvalues=3, maxBasisSize=24, tolerance=1e-8)
+    tr.compute()
+    B = capi.Csr.upload_blocks(ctx, sizes, sizes, blocks)
+    eb = solver.LanczosEigenSolver()
+    eb.setDeviceOperator(B).set(minIterations=30, maxIterations=30)
+    eb.compute()
+    if shards == 1:
+        t = [torch.from_numpy(a).cuda() for a in (rowptr, col, val)]
+        D = capi.Csr.from_device(ctx, N, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr())
+        ed = solver.LanczosEigenSolver(); ed.setDeviceOperator(D).set(minIterations=10, maxIterations=10); ed.compute(); ed.close(); D.close()
+        del t
+    zc = solver.LanczosEigenSolver(np.complex128)
+    zc.setMatrixMultiplication(lambda x: 2.0 * x, 64).set(maxIterations=5)
+    zc.compute()
+    for o in (es, ar, tr, eb, zc):
+        o.close()
+    A.close(); B.close(); ctx.close()
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    free, total = torch.cuda.mem_get_info()
+    if r == 2:
+        free0 = free  # after the first rounds: allocator pools and lazy runtime state are warm
+    if r % 10 == 9 or r == rounds - 1:
+        print(f"round {r+1}: free {free/2**20:.0f} MiB" + (f"  (delta vs round 3: {(free-free0)/2**20:+.1f} MiB)" if free0 else ""), flush=True)
+assert free0 is not None and free0 - free < 64 * 2**20, "device memory is leaking"
+print("soak ok")
