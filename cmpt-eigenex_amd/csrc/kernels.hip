@@ -805,9 +805,8 @@ __global__ void k_sum_shards(PtrPack bufs, int nshards, int n) {
 }
 
 // ---- scalar finalisers -----------------------------------------------------
-__global__ void k_fin_norm(Ctrl* ctrl, const double* nrm2, double threshold, int mode, double* beta) {
-  if (threadIdx.x != 0 || ctrl->stopped) return;
-  const double nrm = sqrt(*nrm2);
+__device__ __forceinline__ void fin_norm_apply(Ctrl* ctrl, double nrm2, double threshold, int mode, double* beta) {
+  const double nrm = sqrt(nrm2);
   if (mode == kFinInit) {
     if (nrm < threshold) {  // lanczos.hpp:316-318, arnoldi.hpp:262-264
       ctrl->stopped = 1;
@@ -824,13 +823,45 @@ __global__ void k_fin_norm(Ctrl* ctrl, const double* nrm2, double threshold, int
     ctrl->residue = nrm;  // arnoldi.hpp:348, :385
   }
 }
-
-__global__ void k_fin_alpha(Ctrl* ctrl, const double* val, double* alpha, int first) {
+__global__ void k_fin_norm(Ctrl* ctrl, const double* nrm2, double threshold, int mode, double* beta) {
   if (threadIdx.x != 0 || ctrl->stopped) return;
-  alpha[ctrl->nalpha++] = *val;  // lanczos.hpp:395, :448
+  fin_norm_apply(ctrl, *nrm2, threshold, mode, beta);
+}
+
+__device__ __forceinline__ void fin_alpha_apply(Ctrl* ctrl, double val, double* alpha, int first);
+
+// Second-stage sum of ONE scalar (ncomp = 1) or a (re, im) pair and the step decision that follows it, in one
+// launch: used when nothing has to be all-reduced in between (one shard, no communicator).  Same sums as k_reduce,
+// same decisions as k_fin_norm / k_fin_alpha; two dependent tiny launches (~4-5 us each on the device) become one.
+__global__ __launch_bounds__(kBlock) void k_reduce_fin(const double* __restrict__ partials, int pstride, int nblocks,
+                                                       int ncomp, double* __restrict__ out, Ctrl* ctrl, int mode,
+                                                       double* series, double threshold) {
+  __shared__ double lds4[4];
+  if (ctrl->stopped) return;
+  double v[2] = {0.0, 0.0};
+  for (int c = 0; c < ncomp; ++c) {
+    const double* p = partials + (int64_t)c * pstride;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += kBlock) s += p[b];
+    v[c] = block_sum(s, lds4);
+  }
+  if (threadIdx.x != 0) return;
+  for (int c = 0; c < ncomp; ++c) out[c] = v[c];
+  if (mode == kFinishAlpha || mode == kFinishAlphaFirst)
+    fin_alpha_apply(ctrl, v[0], series, mode == kFinishAlphaFirst);
+  else
+    fin_norm_apply(ctrl, v[0], threshold, mode, series);
+}
+
+__device__ __forceinline__ void fin_alpha_apply(Ctrl* ctrl, double val, double* alpha, int first) {
+  alpha[ctrl->nalpha++] = val;  // lanczos.hpp:395, :448
   ctrl->nvec++;
   ctrl->calls_true++;
   if (!first) ctrl->iterations++;  // lanczos.hpp:450 (not on the first call, :378-398)
+}
+__global__ void k_fin_alpha(Ctrl* ctrl, const double* val, double* alpha, int first) {
+  if (threadIdx.x != 0 || ctrl->stopped) return;
+  fin_alpha_apply(ctrl, *val, alpha, first);
 }
 
 __global__ void k_arnoldi_begin(Ctrl* ctrl, double threshold, int64_t n_global, int cap, double* H, int ldh, int es) {
@@ -1203,6 +1234,11 @@ void launch_pack(hipStream_t s, const double* x, const int32_t* idx, int64_t cou
 void launch_sum_shards(hipStream_t s, const PtrPack& bufs, int nshards, int n) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_sum_shards, dim3((n + 63) / 64), dim3(64), 0, s, bufs, nshards, n);
+}
+
+void launch_reduce_fin(hipStream_t s, const double* partials, int pstride, int nblocks, int ncomp, double* out, Ctrl* ctrl,
+                       int mode, double* series, double threshold) {
+  hipLaunchKernelGGL(k_reduce_fin, dim3(1), dim3(kBlock), 0, s, partials, pstride, nblocks, ncomp, out, ctrl, mode, series, threshold);
 }
 
 void launch_fin_norm(hipStream_t s, Ctrl* ctrl, const double* nrm2, double threshold, int mode, double* beta) {

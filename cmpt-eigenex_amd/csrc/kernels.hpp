@@ -109,6 +109,11 @@ void launch_sum_shards(hipStream_t s, const PtrPack& bufs, int nshards, int n);
 
 // ---- scalar finalisers (one thread) ----
 enum FinNormMode { kFinInit = 0, kFinLanczos = 1, kFinArnoldi = 2 };
+enum FinAlphaMode { kFinishAlpha = 8, kFinishAlphaFirst = 9 };
+// one launch for "sum the per-block partials of one scalar / (re, im) pair" + the decision k_fin_norm (mode = a
+// FinNormMode, series = beta) or k_fin_alpha (mode = a FinAlphaMode, series = alpha) takes from it
+void launch_reduce_fin(hipStream_t s, const double* partials, int pstride, int nblocks, int ncomp, double* out, Ctrl* ctrl,
+                       int mode, double* series, double threshold);
 // nrm2 = ||w||^2 (all-reduced).  kFinInit: fail if sqrt < threshold, else scale = 1/nrm.
 // kFinLanczos: beta.push_back(sqrt); breakdown if <= threshold else scale = 1/beta.
 // kFinArnoldi: residue = sqrt.

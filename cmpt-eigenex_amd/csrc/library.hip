@@ -707,8 +707,14 @@ int enq_dots(eigenex_basis_s* b, int src_ref, bool three_term, int k, int first,
 }
 
 // dst = w0(src, tt) - sum h[slot+c]*col_c ; hbuf[slot_nrm] = all-reduced ||dst||^2 (if want_norm)
+// one shard and no communicator: nothing is all-reduced between a partial sum and the decision taken from it, so the
+// second-stage sum and the decision share one launch (k_reduce_fin)
+inline bool decides_locally(const eigenex_basis_s* b) { return b->ctx->P == 1 && !b->ctx->comm; }
+
+// fin_mode >= 0 (a FinNormMode; only with want_norm, the state's control block and decides_locally): the norm's
+// second-stage sum also takes the step decision
 int enq_update(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_term, int k, int first, int stride, int count,
-               int qfirst, int nq, int slot, bool want_norm, int use_ctrl, int base = 0, int nrm_slot = -1) {
+               int qfirst, int nq, int slot, bool want_norm, int use_ctrl, int base = 0, int nrm_slot = -1, int fin_mode = -1) {
   if (nrm_slot < 0) nrm_slot = b->slot_nrm();
   eigenex_context_s* c = b->ctx;
   const int ncols = count + nq;
@@ -724,10 +730,13 @@ int enq_update(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_term, in
     }
     if (want_norm) {
       ProfScope ps(c, EIGENEX_K_SMALL, 0.0);
-      launch_reduce(c->stream, s.partials, s.pstride, s.g_vec, 1, s.hbuf + nrm_slot, ctl);
+      if (fin_mode >= 0)
+        launch_reduce_fin(c->stream, s.partials, s.pstride, s.g_vec, 1, s.hbuf + nrm_slot, s.ctrl, fin_mode, s.beta, b->threshold);
+      else
+        launch_reduce(c->stream, s.partials, s.pstride, s.g_vec, 1, s.hbuf + nrm_slot, ctl);
     }
   }
-  return want_norm ? allreduce(b, nrm_slot, 1) : 0;
+  return want_norm && fin_mode < 0 ? allreduce(b, nrm_slot, 1) : 0;
 }
 
 // Gram-Schmidt of the vector in src against the selected columns, result in dst,
@@ -736,8 +745,12 @@ int enq_update(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_term, in
 // vectors before the basis vectors (Arnoldi, arnoldi.hpp:373-383) or after (Lanczos,
 // lanczos.hpp:416-425).
 // norm_before: hbuf[slot_nrm_before] holds the all-reduced ||src||^2 (adaptive scheme only)
+// fin_mode (a FinNormMode) names the decision the caller takes from the norm; when it can ride on the norm's second
+// stage (*fin_merged = true) the caller must not launch k_fin_norm itself
 int enq_orthogonalize(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_term, int k, int first, int stride,
-                      int count, int nq, bool q_first, bool norm_before = false) {
+                      int count, int nq, bool q_first, bool norm_before = false, int fin_mode = -1, bool* fin_merged = nullptr) {
+  const int merge = (fin_mode >= 0 && fin_merged && decides_locally(b)) ? fin_mode : -1;
+  if (fin_merged) *fin_merged = false;
   int mode = b->ortho_mode;
   if (mode == EIGENEX_ORTHO_BATCHED_ADAPTIVE && (three_term || count + nq == 0)) mode = EIGENEX_ORTHO_BATCHED;
   if (mode == EIGENEX_ORTHO_BATCHED_ADAPTIVE && !norm_before) mode = EIGENEX_ORTHO_BATCHED_TWICE;
@@ -760,8 +773,11 @@ int enq_orthogonalize(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_t
   if (mode == EIGENEX_ORTHO_BATCHED || mode == EIGENEX_ORTHO_BATCHED_TWICE) {
     const bool twice = mode == EIGENEX_ORTHO_BATCHED_TWICE && count + nq > 0;
     CHK(enq_dots(b, src_ref, three_term, k, first, stride, count, 0, nq, 0, true));
-    CHK(enq_update(b, src_ref, dst_ref, three_term, k, first, stride, count, 0, nq, 0, !twice, true));
-    if (!twice) return 0;
+    CHK(enq_update(b, src_ref, dst_ref, three_term, k, first, stride, count, 0, nq, 0, !twice, true, 0, -1, twice ? -1 : merge));
+    if (!twice) {
+      if (merge >= 0) *fin_merged = true;
+      return 0;
+    }
     // second pass on the result itself ("twice is enough"): h += V^H w, w -= V (V^H w)
     CHK(enq_dots(b, dst_ref, false, 0, first, stride, count, 0, nq, 0, true, b->base_h2()));
     CHK(enq_update(b, dst_ref, dst_ref, false, 0, first, stride, count, 0, nq, 0, true, true, b->base_h2()));
@@ -770,19 +786,20 @@ int enq_orthogonalize(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_t
   }
   // sequential modified Gram-Schmidt
   const int total = count + nq;
-  CHK(enq_update(b, src_ref, dst_ref, three_term, k, 0, 1, 0, 0, 0, 0, total == 0, true));
+  CHK(enq_update(b, src_ref, dst_ref, three_term, k, 0, 1, 0, 0, 0, 0, total == 0, true, 0, -1, total == 0 ? merge : -1));
+  if (merge >= 0) *fin_merged = true;  // the last update below (or the one above) carries the decision
   int done = 0;
   auto one_q = [&](int q) -> int {
     const int slot = count + q;
     CHK(enq_dots(b, dst_ref, false, 0, 0, 1, 0, q, 1, slot, true));
     ++done;
-    return enq_update(b, dst_ref, dst_ref, false, 0, 0, 1, 0, q, 1, slot, done == total, true);
+    return enq_update(b, dst_ref, dst_ref, false, 0, 0, 1, 0, q, 1, slot, done == total, true, 0, -1, done == total ? merge : -1);
   };
   auto one_v = [&](int i) -> int {
     const int slot = i;
     CHK(enq_dots(b, dst_ref, false, 0, first + i * stride, 1, 1, 0, 0, slot, true));
     ++done;
-    return enq_update(b, dst_ref, dst_ref, false, 0, first + i * stride, 1, 1, 0, 0, slot, done == total, true);
+    return enq_update(b, dst_ref, dst_ref, false, 0, first + i * stride, 1, 1, 0, 0, slot, done == total, true, 0, -1, done == total ? merge : -1);
   };
   if (q_first)
     for (int q = 0; q < nq; ++q) CHK(one_q(q));
@@ -820,8 +837,12 @@ void launch_operator(hipStream_t st, const CsrShard* m, int es, const double* x_
 // v = (A + shift) * (w*scale), basis column `ucol` = w*scale, optional alpha = u.v -> hbuf[slot_alpha]
 // Returns 1 in *skipped if the device had already stopped (host-operator path only).
 // self_norm (instead of want_dot, device operators only): hbuf[slot_nrm_before] = all-reduced ||v||^2
-int enq_apply(eigenex_basis_s* b, int ucol, bool want_dot, bool self_norm = false) {
+// alpha_mode (a FinAlphaMode, with want_dot): as for enq_orthogonalize, *fin_merged tells the caller that k_fin_alpha
+// has been taken care of
+int enq_apply(eigenex_basis_s* b, int ucol, bool want_dot, bool self_norm = false, int alpha_mode = -1, bool* fin_merged = nullptr) {
   eigenex_context_s* c = b->ctx;
+  const int merge = (want_dot && alpha_mode >= 0 && fin_merged && b->csr && decides_locally(b)) ? alpha_mode : -1;
+  if (fin_merged) *fin_merged = merge >= 0;
   if (b->csr) {
     CHK(halo_exchange(b));
     for (auto& s : b->sh) {
@@ -844,11 +865,14 @@ int enq_apply(eigenex_basis_s* b, int ucol, bool want_dot, bool self_norm = fals
       }
       if (want_dot) {
         ProfScope ps(c, EIGENEX_K_SMALL, 0.0);
-        launch_reduce(c->stream, s.partials, s.pstride, s.g_spmv, b->es, s.hbuf + b->slot_alpha(), s.ctrl);
+        if (merge >= 0)
+          launch_reduce_fin(c->stream, s.partials, s.pstride, s.g_spmv, b->es, s.hbuf + b->slot_alpha(), s.ctrl, merge, s.alpha, 0.0);
+        else
+          launch_reduce(c->stream, s.partials, s.pstride, s.g_spmv, b->es, s.hbuf + b->slot_alpha(), s.ctrl);
       }
     }
     if (self_norm) return allreduce(b, b->slot_nrm_before(), 1);
-    return want_dot ? allreduce(b, b->slot_alpha(), b->es) : 0;
+    return want_dot && merge < 0 ? allreduce(b, b->slot_alpha(), b->es) : 0;
   }
   // operator lives in host code (MatMulFunction, lanczos.hpp:116): stage through pinned memory
   if (!b->fn) return fail(EIGENEX_ERR_STATE, "no operator: neither a CSR handle nor a host callback is set");
@@ -874,9 +898,10 @@ int enq_apply(eigenex_basis_s* b, int ucol, bool want_dot, bool self_norm = fals
 // setInitialLanczosvector / setInitialArnoldivector (lanczos.hpp:299-323, arnoldi.hpp:245-269):
 // the start vector sits in W; deflate by orthogonalizingVectors_, norm, fail or scale = 1/norm.
 int enq_initial_vector(eigenex_basis_s* b) {
-  CHK(enq_orthogonalize(b, EIGENEX_VEC_W, EIGENEX_VEC_W, false, 0, 0, 1, 0, b->nq, true));
-  for (auto& s : b->sh)
-    launch_fin_norm(b->ctx->stream, s.ctrl, s.hbuf + b->slot_nrm(), b->threshold, kFinInit, s.beta);
+  bool merged = false;
+  CHK(enq_orthogonalize(b, EIGENEX_VEC_W, EIGENEX_VEC_W, false, 0, 0, 1, 0, b->nq, true, false, kFinInit, &merged));
+  if (!merged)
+    for (auto& s : b->sh) launch_fin_norm(b->ctx->stream, s.ctrl, s.hbuf + b->slot_nrm(), b->threshold, kFinInit, s.beta);
   return 0;
 }
 
@@ -886,8 +911,10 @@ int lanczos_call(eigenex_basis_s* b) {
   if (!b->started) {
     b->started = true;
     CHK(enq_initial_vector(b));
-    CHK(enq_apply(b, 0, true));  // :389-392
-    for (auto& s : b->sh) launch_fin_alpha(st, s.ctrl, s.hbuf + b->slot_alpha(), s.alpha, 1, b->cap);  // :395
+    bool merged = false;
+    CHK(enq_apply(b, 0, true, false, kFinishAlphaFirst, &merged));  // :389-392
+    if (!merged)
+      for (auto& s : b->sh) launch_fin_alpha(st, s.ctrl, s.hbuf + b->slot_alpha(), s.alpha, 1, b->cap);  // :395
     b->h_nvec = 1;
     return 0;
   }
@@ -903,10 +930,13 @@ int lanczos_call(eigenex_basis_s* b) {
     count = kmod < nk - 1 ? (int)((nk - 1 - kmod + b->interval - 1) / b->interval) : 0;
     nq = kmod == 0 ? b->nq : 0;
   }
-  CHK(enq_orthogonalize(b, EIGENEX_VEC_V, EIGENEX_VEC_W, true, k, first, stride, count, nq, false));
-  for (auto& s : b->sh) launch_fin_norm(st, s.ctrl, s.hbuf + b->slot_nrm(), b->threshold, kFinLanczos, s.beta);  // :429-437
-  CHK(enq_apply(b, k + 1, true));  // :439-445
-  for (auto& s : b->sh) launch_fin_alpha(st, s.ctrl, s.hbuf + b->slot_alpha(), s.alpha, 0, b->cap);  // :448-450
+  bool merged = false;
+  CHK(enq_orthogonalize(b, EIGENEX_VEC_V, EIGENEX_VEC_W, true, k, first, stride, count, nq, false, false, kFinLanczos, &merged));
+  if (!merged)
+    for (auto& s : b->sh) launch_fin_norm(st, s.ctrl, s.hbuf + b->slot_nrm(), b->threshold, kFinLanczos, s.beta);  // :429-437
+  CHK(enq_apply(b, k + 1, true, false, kFinishAlpha, &merged));  // :439-445
+  if (!merged)
+    for (auto& s : b->sh) launch_fin_alpha(st, s.ctrl, s.hbuf + b->slot_alpha(), s.alpha, 0, b->cap);  // :448-450
   b->h_nvec++;
   return 0;
 }
