@@ -904,6 +904,53 @@ __global__ void k_select_norm(const Ctrl* pass2, const double* nrm2_first, const
   *nrm2_final = pass2->stopped ? *nrm2_first : *nrm2_second;
 }
 
+// One shard: the sum of the first pass's norm partials and the DGKS decision in one launch
+__global__ __launch_bounds__(kBlock) void k_reduce_decide(const double* __restrict__ partials, int nblocks, double* nrm2_first,
+                                                          const Ctrl* ctrl, Ctrl* pass2, const double* nrm2_before, double eta2) {
+  __shared__ double lds4[4];
+  double s = 0.0;
+  if (!ctrl->stopped)
+    for (int b = threadIdx.x; b < nblocks; b += kBlock) s += partials[b];
+  s = block_sum(s, lds4);
+  if (threadIdx.x != 0) return;
+  if (ctrl->stopped) {
+    pass2->stopped = 1;
+    return;
+  }
+  *nrm2_first = s;
+  pass2->stopped = (s < eta2 * *nrm2_before) ? 0 : 1;
+}
+
+// One shard: everything that follows the (conditional) second pass of an Arnoldi step in one launch -- the second
+// norm's sum, h += h2, the choice of the norm, residue = sqrt(norm) (k_fin_norm, kFinArnoldi) and k_arnoldi_end.
+__global__ __launch_bounds__(kBlock) void k_arnoldi_tail(const double* __restrict__ partials, int nblocks, Ctrl* ctrl,
+                                                         const Ctrl* pass2, double* h, const double* h2, int ncoef,
+                                                         const double* nrm2_first, double* nrm2_final, double* H, int ldh, int es) {
+  __shared__ double lds4[4];
+  if (ctrl->stopped) return;
+  const bool second = pass2->stopped == 0;
+  double s = 0.0;
+  if (second)
+    for (int b = threadIdx.x; b < nblocks; b += kBlock) s += partials[b];
+  s = block_sum(s, lds4);
+  if (second)
+    for (int i = threadIdx.x; i < ncoef; i += kBlock) h[i] += h2[i];
+  __syncthreads();
+  const int k = ctrl->nvec;  // index of the vector just added
+  for (int i = threadIdx.x; i < (k + 1) * es; i += kBlock) H[(int64_t)k * ldh * es + i] = h[i];  // arnoldi.hpp:380-383
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double nrm2 = second ? s : *nrm2_first;
+    *nrm2_final = nrm2;
+    ctrl->residue = sqrt(nrm2);  // arnoldi.hpp:348, :385
+    for (int e = 0; e < es; ++e) H[((int64_t)k * ldh + k + 1) * es + e] = 0.0;  // arnoldi.hpp:384
+    ctrl->nvec = k + 1;
+    ctrl->nalpha = k + 1;
+    ctrl->iterations++;
+    ctrl->calls_true++;
+  }
+}
+
 // dst[i] += src[i] (coefficients of a second Gram-Schmidt pass folded into the first)
 __global__ void k_add_small(double* dst, const double* src, int n, const Ctrl* ctrl) {
   if (ctrl->stopped) return;
@@ -1263,6 +1310,16 @@ void launch_decide_second_pass(hipStream_t s, const Ctrl* ctrl, Ctrl* pass2, con
 }
 void launch_select_norm(hipStream_t s, const Ctrl* pass2, const double* nrm2_first, const double* nrm2_second, double* nrm2_final) {
   hipLaunchKernelGGL(k_select_norm, dim3(1), dim3(64), 0, s, pass2, nrm2_first, nrm2_second, nrm2_final);
+}
+
+void launch_reduce_decide(hipStream_t s, const double* partials, int nblocks, double* nrm2_first, const Ctrl* ctrl, Ctrl* pass2,
+                          const double* nrm2_before, double eta2) {
+  hipLaunchKernelGGL(k_reduce_decide, dim3(1), dim3(kBlock), 0, s, partials, nblocks, nrm2_first, ctrl, pass2, nrm2_before, eta2);
+}
+void launch_arnoldi_tail(hipStream_t s, const double* partials, int nblocks, Ctrl* ctrl, const Ctrl* pass2, double* h, const double* h2,
+                         int ncoef, const double* nrm2_first, double* nrm2_final, double* H, int ldh, int es) {
+  hipLaunchKernelGGL(k_arnoldi_tail, dim3(1), dim3(kBlock), 0, s, partials, nblocks, ctrl, pass2, h, h2, ncoef, nrm2_first, nrm2_final, H,
+                     ldh, es);
 }
 
 void launch_add_small(hipStream_t s, double* dst, const double* src, int n, const Ctrl* ctrl) {

@@ -129,6 +129,11 @@ void launch_add_small(hipStream_t s, double* dst, const double* src, int n, cons
 // adaptive second Gram-Schmidt pass: pass2->stopped = !(nrm2_after < eta2*nrm2_before) (or ctrl stopped)
 void launch_decide_second_pass(hipStream_t s, const Ctrl* ctrl, Ctrl* pass2, const double* nrm2_before, const double* nrm2_after, double eta2);
 void launch_select_norm(hipStream_t s, const Ctrl* pass2, const double* nrm2_first, const double* nrm2_second, double* nrm2_final);
+// single-shard merges of the tiny launches around the conditional second pass (see kernels.hip)
+void launch_reduce_decide(hipStream_t s, const double* partials, int nblocks, double* nrm2_first, const Ctrl* ctrl, Ctrl* pass2,
+                          const double* nrm2_before, double eta2);
+void launch_arnoldi_tail(hipStream_t s, const double* partials, int nblocks, Ctrl* ctrl, const Ctrl* pass2, double* h, const double* h2,
+                         int ncoef, const double* nrm2_first, double* nrm2_final, double* H, int ldh, int es);
 void launch_restart_fix(hipStream_t s, Ctrl* ctrl, double* alpha, double* beta, int m, int nkeep, double coupling_last);
 // vector accepted into the basis: ++nvec  (after the operator has been applied with `scale`)
 void launch_accept_vector(hipStream_t s, Ctrl* ctrl);

@@ -754,6 +754,21 @@ int enq_orthogonalize(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_t
   int mode = b->ortho_mode;
   if (mode == EIGENEX_ORTHO_BATCHED_ADAPTIVE && (three_term || count + nq == 0)) mode = EIGENEX_ORTHO_BATCHED;
   if (mode == EIGENEX_ORTHO_BATCHED_ADAPTIVE && !norm_before) mode = EIGENEX_ORTHO_BATCHED_TWICE;
+  if (mode == EIGENEX_ORTHO_BATCHED_ADAPTIVE && fin_mode == kFinArnoldi && fin_merged && decides_locally(b)) {
+    // one shard: the tiny launches around the conditional second pass are merged (k_reduce_decide, k_arnoldi_tail);
+    // the caller launches neither k_fin_norm nor k_arnoldi_end
+    hipStream_t st = b->ctx->stream;
+    BasisShard& s = b->sh[0];
+    CHK(enq_dots(b, src_ref, false, 0, first, stride, count, 0, nq, 0, 1));
+    CHK(enq_update(b, src_ref, dst_ref, false, 0, first, stride, count, 0, nq, 0, false, 1));
+    launch_reduce_decide(st, s.partials, s.g_vec, s.hbuf + b->slot_nrm_first(), s.ctrl, s.ctrl_pass2, s.hbuf + b->slot_nrm_before(), 0.5);
+    CHK(enq_dots(b, dst_ref, false, 0, first, stride, count, 0, nq, 0, 2, b->base_h2()));
+    CHK(enq_update(b, dst_ref, dst_ref, false, 0, first, stride, count, 0, nq, 0, false, 2, b->base_h2()));
+    launch_arnoldi_tail(st, s.partials, s.g_vec, s.ctrl, s.ctrl_pass2, s.hbuf, s.hbuf + b->base_h2(), (count + nq) * b->es,
+                        s.hbuf + b->slot_nrm_first(), s.hbuf + b->slot_nrm(), s.H, b->ldh, b->es);
+    *fin_merged = true;
+    return 0;
+  }
   if (mode == EIGENEX_ORTHO_BATCHED_ADAPTIVE) {
     hipStream_t st = b->ctx->stream;
     CHK(enq_dots(b, src_ref, false, 0, first, stride, count, 0, nq, 0, 1));
@@ -959,11 +974,16 @@ int arnoldi_call(eigenex_basis_s* b) {
   CHK(enq_apply(b, k, false, adaptive));  // :333-336, :369-372
   if (!b->csr && b->shift != 0.0) { /* shift applied inside enq_apply's host path */ }
   // :337-345, :373-383
-  CHK(enq_orthogonalize(b, EIGENEX_VEC_V, EIGENEX_VEC_W, false, 0, 0, 1, k + 1, b->nq, true, adaptive));
-  for (auto& s : b->sh) {
-    launch_fin_norm(st, s.ctrl, s.hbuf + b->slot_nrm(), b->threshold, kFinArnoldi, s.beta);  // :348, :385
-    launch_arnoldi_end(st, s.ctrl, s.hbuf, s.H, b->ldh, b->es);
-  }
+  bool tail_done = false;  // only the adaptive scheme on one shard folds k_fin_norm and k_arnoldi_end into its last launch
+  if (adaptive)
+    CHK(enq_orthogonalize(b, EIGENEX_VEC_V, EIGENEX_VEC_W, false, 0, 0, 1, k + 1, b->nq, true, true, kFinArnoldi, &tail_done));
+  else
+    CHK(enq_orthogonalize(b, EIGENEX_VEC_V, EIGENEX_VEC_W, false, 0, 0, 1, k + 1, b->nq, true));
+  if (!tail_done)
+    for (auto& s : b->sh) {
+      launch_fin_norm(st, s.ctrl, s.hbuf + b->slot_nrm(), b->threshold, kFinArnoldi, s.beta);  // :348, :385
+      launch_arnoldi_end(st, s.ctrl, s.hbuf, s.H, b->ldh, b->es);
+    }
   b->h_nvec = k + 1;
   return 0;
 }
