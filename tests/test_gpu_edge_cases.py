@@ -69,3 +69,42 @@ def test_tiny_and_degenerate_systems(mods, shards):
     eb.compute()
     np.testing.assert_array_equal(eb.results()["eigenvalues"], r["eigenvalues"])
     ctx.close()
+
+
+def test_two_contexts_driven_from_two_threads(mods):
+    """include/eigenex_hip.h: handles are not thread-safe, but different contexts may be driven from different threads
+    (one HIP stream each, thread-local error text).  Two threads solve different problems at the same time (ctypes
+    releases the GIL inside the calls); results equal the serial ones bit for bit."""
+    import threading
+
+    capi, solver = mods
+    from oracle import cref
+
+    def solve(n, m, out, key):
+        try:
+            ctx = capi.Context()
+            A = capi.Csr.laplacian3d(ctx, n)
+            es = solver.LanczosEigenSolver()
+            es.setDeviceOperator(A).set(minIterations=m, maxIterations=m, computeEigenvectorsOn=0,
+                                        initialVector=np.random.default_rng(n).standard_normal(n ** 3))
+            for _ in range(3):
+                es.compute()
+            r = es.results()
+            out[key] = (r["alpha"].copy(), r["beta"].copy())
+            es.close(); A.close(); ctx.close()
+        except Exception as e:  # pragma: no cover
+            out[key] = e
+
+    serial, threaded = {}, {}
+    jobs = [(40, 60), (48, 45)]
+    for n, m in jobs:
+        solve(n, m, serial, n)
+    ts = [threading.Thread(target=solve, args=(n, m, threaded, n)) for n, m in jobs]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for n, _ in jobs:
+        assert not isinstance(threaded[n], Exception), threaded[n]
+        np.testing.assert_array_equal(threaded[n][0], serial[n][0])
+        np.testing.assert_array_equal(threaded[n][1], serial[n][1])
