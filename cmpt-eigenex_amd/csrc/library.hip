@@ -218,6 +218,22 @@ struct BasisShard {
 
 }  // namespace
 
+// A batch of step calls recorded as a hipGraph (see enqueue_steps): replayed when the same batch is asked for again
+// from the same state with the same settings -- repeated solves of one size, e.g. Krylov time stepping.
+struct StepGraphKey {
+  int kind, started, h_nvec, ncalls, ortho_mode, nq, flags, g_vec, g_spmv, cap;
+  int64_t interval;
+  double threshold, shift, shift_im;
+  const void* slab;
+};
+struct StepGraph {
+  StepGraphKey key;
+  hipGraphExec_t exec = nullptr;
+  bool started_after = false;
+  int h_nvec_after = 0;
+  uint64_t last_use = 0;
+};
+
 struct eigenex_basis_s {
   eigenex_context_s* ctx = nullptr;
   eigenex_csr_s* csr = nullptr;
@@ -234,6 +250,8 @@ struct eigenex_basis_s {
   void* fn_user = nullptr;
   double *pin_in = nullptr, *pin_out = nullptr;
   Ctrl* pin_ctrl = nullptr;
+  std::vector<StepGraph> graphs;
+  uint64_t graph_clock = 0;
   // offsets (in doubles) into hbuf behind the es*maxcols coefficient entries
   int slot_nrm() const { return es * maxcols; }
   int slot_alpha() const { return es * maxcols + 1; }  // (re, im) for complex
@@ -988,6 +1006,79 @@ int arnoldi_call(eigenex_basis_s* b) {
   return 0;
 }
 
+// Enqueue `ncalls` step calls (kind 0 Lanczos, 1 Arnoldi).  On a context without a communicator, with a device
+// operator and profiling off, the batch is captured into a hipGraph the first time and replayed afterwards: a dependent
+// launch costs 2.8 us from the stream and 1.7 us as a graph node (scripts/microbench/graph_vs_launch.hip), and the host
+// no longer prepares ~6 launches per step.  Anything that changes what a launch would look like is part of the key.
+constexpr int kMaxStepGraphs = 8;
+constexpr int kMinGraphCalls = 4;
+
+void drop_step_graphs(eigenex_basis_s* b) {
+  for (auto& g : b->graphs)
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  b->graphs.clear();
+}
+
+int enqueue_steps(eigenex_basis_s* b, int ncalls, int kind) {
+  auto plain = [&]() -> int {
+    for (int i = 0; i < ncalls; ++i) CHK(kind == 0 ? lanczos_call(b) : arnoldi_call(b));
+    return 0;
+  };
+  eigenex_context_s* c = b->ctx;
+  static const bool graphs_on = std::getenv("EIGENEX_NO_GRAPHS") == nullptr;
+  if (!graphs_on || !b->csr || c->comm || c->profiling || ncalls < kMinGraphCalls) return plain();
+  StepGraphKey key;
+  std::memset(&key, 0, sizeof(key));
+  key.kind = kind, key.started = b->started ? 1 : 0, key.h_nvec = b->h_nvec, key.ncalls = ncalls, key.ortho_mode = b->ortho_mode;
+  key.nq = b->nq, key.flags = b->sh[0].spmv_flags, key.g_vec = b->sh[0].g_vec, key.g_spmv = b->sh[0].g_spmv, key.cap = b->cap;
+  key.interval = b->interval, key.threshold = b->threshold, key.shift = b->shift, key.shift_im = b->shift_im, key.slab = b->sh[0].V;
+  for (auto& g : b->graphs)
+    if (std::memcmp(&g.key, &key, sizeof(key)) == 0) {
+      HIPCHK(hipGraphLaunch(g.exec, c->stream));
+      b->started = g.started_after;
+      b->h_nvec = g.h_nvec_after;
+      g.last_use = ++b->graph_clock;
+      return 0;
+    }
+  // record: nothing executes during the capture; the host-side counters advance as in a plain run
+  const bool started0 = b->started;
+  const int h_nvec0 = b->h_nvec;
+  if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    return plain();
+  }
+  const int rc = plain();
+  const std::string err = g_err;
+  hipGraph_t graph = nullptr;
+  const hipError_t ec = hipStreamEndCapture(c->stream, &graph);
+  hipGraphExec_t exec = nullptr;
+  if (rc == 0 && ec == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+    (void)hipGraphDestroy(graph);
+    if ((int)b->graphs.size() >= kMaxStepGraphs) {  // evict the least recently used
+      size_t victim = 0;
+      for (size_t i = 1; i < b->graphs.size(); ++i)
+        if (b->graphs[i].last_use < b->graphs[victim].last_use) victim = i;
+      (void)hipGraphExecDestroy(b->graphs[victim].exec);
+      b->graphs.erase(b->graphs.begin() + (std::ptrdiff_t)victim);
+    }
+    StepGraph g;
+    g.key = key, g.exec = exec, g.started_after = b->started, g.h_nvec_after = b->h_nvec, g.last_use = ++b->graph_clock;
+    b->graphs.push_back(g);
+    HIPCHK(hipGraphLaunch(exec, c->stream));
+    return 0;
+  }
+  // the batch could not be recorded (or a call failed while recording): nothing has run yet, so rewind and run it plainly
+  if (graph) (void)hipGraphDestroy(graph);
+  (void)hipGetLastError();
+  b->started = started0;
+  b->h_nvec = h_nvec0;
+  if (rc != 0) {
+    g_err = err;
+    return rc;  // the same argument/state error a plain run reports, before anything was launched
+  }
+  return plain();
+}
+
 int sync_ctrl(eigenex_basis_s* b, Ctrl* out) {
   eigenex_context_s* c = b->ctx;
   HIPCHK(hipMemcpyAsync(b->pin_ctrl, b->sh[0].ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, c->stream));
@@ -1540,6 +1631,7 @@ int eigenex_basis_destroy(eigenex_basis_t b) {
   if (!b) return 0;
   (void)hipSetDevice(b->ctx->device);
   (void)hipStreamSynchronize(b->ctx->stream);
+  drop_step_graphs(b);
   for (auto& s : b->sh) {
     for (void* p : {(void*)s.V, (void*)s.Q, (void*)s.v, (void*)s.w, (void*)s.start, (void*)s.partials, (void*)s.hbuf, (void*)s.alpha,
                     (void*)s.beta, (void*)s.H, (void*)s.X, (void*)s.ctrl, (void*)s.ctrl_zero, (void*)s.ctrl_pass2})
@@ -1675,6 +1767,8 @@ int eigenex_basis_reserve(eigenex_basis_t b, int capacity) {
   if (capacity <= b->cap) return 0;
   eigenex_context_s* c = b->ctx;
   HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  drop_step_graphs(b);  // recorded batches point into the arrays that are replaced below
   const int oldcap = b->cap, oldldh = b->ldh;
   const int newmax = capacity + b->nq, newldh = capacity + 2;
   for (auto& s : b->sh) {
@@ -1899,8 +1993,7 @@ int eigenex_scale(eigenex_basis_t b, int dst_ref, int src_ref, double sc) {
 int eigenex_lanczos_enqueue(eigenex_basis_t b, int ncalls) {
   if (!b || ncalls < 0) return fail(EIGENEX_ERR_ARG, "bad argument");
   HIPCHK(hipSetDevice(b->ctx->device));
-  for (int i = 0; i < ncalls; ++i) CHK(lanczos_call(b));
-  return 0;
+  return enqueue_steps(b, ncalls, 0);
 }
 
 // Thick restart (Wu & Simon): with m+1 Lanczos vectors on the device (u_0..u_m, v = A u_m, alpha[m] known),
@@ -1951,8 +2044,7 @@ int eigenex_lanczos_restart(eigenex_basis_t b, int nkeep, const double* S, int l
 int eigenex_arnoldi_enqueue(eigenex_basis_t b, int ncalls) {
   if (!b || ncalls < 0) return fail(EIGENEX_ERR_ARG, "bad argument");
   HIPCHK(hipSetDevice(b->ctx->device));
-  for (int i = 0; i < ncalls; ++i) CHK(arnoldi_call(b));
-  return 0;
+  return enqueue_steps(b, ncalls, 1);
 }
 
 int eigenex_lanczos_state(eigenex_basis_t b, eigenex_state_t* st, double* alpha, double* beta) {
