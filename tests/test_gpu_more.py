@@ -472,3 +472,42 @@ def test_block_upload_stores_short_sectors_as_csr(mods, monkeypatch):
         b.close()
         A.close()
     ctx.close()
+
+
+def test_replayed_step_graph_with_new_start_vectors(mods):
+    """Repeated solves of one size replay a recorded hipGraph of the step batch (library.hip: enqueue_steps).  The
+    recording holds launches, not data: every replay with a new start vector must match the oracle run from that
+    vector (Krylov time stepping does exactly this), also after the basis has been grown (graphs are dropped)."""
+    capi, solver = mods
+    n, m = 14, 24
+    N = n ** 3
+    rowptr, col, val = cref.laplacian3d(n)
+    ctx = capi.Context()
+    A = capi.Csr.upload(ctx, N, rowptr, col, val)
+    es = solver.LanczosEigenSolver()
+    es.setDeviceOperator(A).set(minIterations=m, maxIterations=m, computeEigenvectorsOn=0)
+    rng = np.random.default_rng(44)
+    for rep in range(4):
+        init = rng.standard_normal(N)
+        es.set(initialVector=init).compute()
+        r = es.results()
+        ref = cref.CLanczos(rowptr, col, val, init, cap=m + 2)
+        assert ref.run(m + 1) == m + 1
+        np.testing.assert_allclose(r["alpha"], ref.alpha, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(r["beta"], ref.beta, rtol=0, atol=1e-12)
+    m2 = m + 30  # a longer run on the same solver: the slab is regrown, the recorded batches are discarded
+    init = rng.standard_normal(N)
+    es.set(minIterations=m2, maxIterations=m2, initialVector=init).compute()
+    ref = cref.CLanczos(rowptr, col, val, init, cap=m2 + 2)
+    assert ref.run(m2 + 1) == m2 + 1
+    np.testing.assert_allclose(es.results()["alpha"], ref.alpha, rtol=0, atol=1e-12)
+    ar = solver.ArnoldiEigenSolver()
+    ar.setDeviceOperator(A).set(minIterations=12, maxIterations=12, computeEigenvectorsOn=0)
+    hs = []
+    for rep in range(3):
+        init = rng.standard_normal(N)
+        ar.set(initialVector=init).compute()
+        c = cref.CArnoldi(rowptr, col, val, init, cap=13)
+        assert c.run(12) == 12
+        np.testing.assert_allclose(ar.results()["hessenberg"][:12, :12], c.hessenberg()[:12, :12], rtol=0, atol=1e-11)
+    ctx.close()
