@@ -245,7 +245,9 @@ int eigenex_scale(eigenex_basis_t b, int dst_ref, int src_ref, double s);
  * Each *_enqueue(b, ncalls) enqueues `ncalls` calls of updateLanczosSteps()/updateArnoldiSteps()
  * WITHOUT host synchronisation; breakdown (beta <= threshold, zero start vector, residue <=
  * threshold) is detected on the device and turns the remaining calls into no-ops, exactly as
- * the reference would have stopped. */
+ * the reference would have stopped.  A batch of >= 4 calls on a device operator (no communicator, profiling off)
+ * is recorded as a hipGraph the first time and replayed when the same batch is enqueued again from the same state
+ * with the same settings (repeated solves of one size); EIGENEX_NO_GRAPHS=1 in the environment turns that off. */
 int eigenex_lanczos_enqueue(eigenex_basis_t b, int ncalls);
 int eigenex_arnoldi_enqueue(eigenex_basis_t b, int ncalls);
 /* Thick restart of a Lanczos run (not in the reference, which has no restart: SURVEY F6; built on the same
