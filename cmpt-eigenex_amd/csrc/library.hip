@@ -1012,6 +1012,8 @@ int arnoldi_call(eigenex_basis_s* b) {
 // no longer prepares ~6 launches per step.  Anything that changes what a launch would look like is part of the key.
 constexpr int kMaxStepGraphs = 8;
 constexpr int kMinGraphCalls = 4;
+constexpr int kMaxGraphCalls = 256;  // x (6..20 launches per call) nodes; the sequential scheme (2j launches per call) is never recorded:
+                                     // a batch of 301 such calls (1.8e5 nodes) crashed the runtime inside the capture
 
 void drop_step_graphs(eigenex_basis_s* b) {
   for (auto& g : b->graphs)
@@ -1026,7 +1028,9 @@ int enqueue_steps(eigenex_basis_s* b, int ncalls, int kind) {
   };
   eigenex_context_s* c = b->ctx;
   static const bool graphs_on = std::getenv("EIGENEX_NO_GRAPHS") == nullptr;
-  if (!graphs_on || !b->csr || c->comm || c->profiling || ncalls < kMinGraphCalls) return plain();
+  if (!graphs_on || !b->csr || c->comm || c->profiling || ncalls < kMinGraphCalls || ncalls > kMaxGraphCalls ||
+      b->ortho_mode == EIGENEX_ORTHO_SEQUENTIAL)
+    return plain();
   StepGraphKey key;
   std::memset(&key, 0, sizeof(key));
   key.kind = kind, key.started = b->started ? 1 : 0, key.h_nvec = b->h_nvec, key.ncalls = ncalls, key.ortho_mode = b->ortho_mode;
