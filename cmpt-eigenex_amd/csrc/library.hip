@@ -1028,9 +1028,9 @@ int enqueue_steps(eigenex_basis_s* b, int ncalls, int kind) {
   };
   eigenex_context_s* c = b->ctx;
   static const bool graphs_on = std::getenv("EIGENEX_NO_GRAPHS") == nullptr;
-  if (!graphs_on || !b->csr || c->comm || c->profiling || ncalls < kMinGraphCalls || ncalls > kMaxGraphCalls ||
+  if (!graphs_on || !b->csr || c->comm || b->sh.size() != 1 || c->profiling || ncalls < kMinGraphCalls || ncalls > kMaxGraphCalls ||
       b->ortho_mode == EIGENEX_ORTHO_SEQUENTIAL)
-    return plain();
+    return plain();  // (the loopback transport multiplies the launches by its shard count and is for verification anyway)
   StepGraphKey key;
   std::memset(&key, 0, sizeof(key));
   key.kind = kind, key.started = b->started ? 1 : 0, key.h_nvec = b->h_nvec, key.ncalls = ncalls, key.ortho_mode = b->ortho_mode;
