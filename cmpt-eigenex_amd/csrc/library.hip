@@ -47,6 +47,15 @@ int fail(int code, const std::string& msg) {
                                         std::to_string(__LINE__) + ")");                                 \
   } while (0)
 
+// a kernel launch reports a bad configuration (e.g. more dynamic LDS than a workgroup may have) only through the
+// runtime's last-error slot: without this check the launch is skipped silently and later kernels read stale data
+#define LAUNCHCHK(what)                                                                                   \
+  do {                                                                                                    \
+    hipError_t e_ = hipGetLastError();                                                                    \
+    if (e_ != hipSuccess)                                                                                 \
+      return fail(EIGENEX_ERR_HIP, std::string(what) + " launch failed: " + hipGetErrorString(e_));       \
+  } while (0)
+
 #define CHK(expr)            \
   do {                       \
     int rc_ = (expr);        \
@@ -59,6 +68,7 @@ inline int64_t pad_rows(int64_t n) { return (n + 63) / 64 * 64; }
 constexpr int kDefaultVecBlocksPerCu = 2;   // in-process A/B at 128^3..512^3: 2 beats 4 by 1-2 % (profiles/)
 constexpr int kDefaultSpmvBlocksPerCu = 4;  // 4 beats 8 by 9 % on the 7-point stencil
 constexpr int kMaxBlocksPerCu = 16;
+constexpr int kDotsMaxAcc = 2048;  // k_dots accumulators per launch: 4 waves x 2048 x 8 B = 64 KB of dynamic LDS
 
 inline void partition(int64_t n, int P, int s, int64_t* b, int64_t* e) {
   *b = (int64_t)((__int128)n * s / P);
@@ -713,10 +723,19 @@ int enq_dots(eigenex_basis_s* b, int src_ref, bool three_term, int k, int first,
     ThreeTerm tt{nullptr, nullptr, nullptr, nullptr};
     if (three_term) tt = ThreeTerm{s.V + (int64_t)k * s.ldd, k > 0 ? s.V + (int64_t)(k - 1) * s.ldd : nullptr, s.alpha + k, s.beta + (k > 0 ? k - 1 : 0)};
     const Ctrl* ctl = pick_ctrl(s, use_ctrl);
-    {
-      ProfScope ps(c, EIGENEX_K_DOTS, use_ctrl == 2 ? 0.0 : 8.0 * s.nd * ncols + 8.0 * s.nd);  // a conditional pass books no bytes
-      launch_dots(c->stream, vec_ptr(s, b->cap, b->nq, src_ref), tt, colset(s, first, stride, count, qfirst, nq), s.nd,
-                  s.partials, s.pstride, s.g_vec, ctl, b->es == 2);
+    // k_dots keeps four per-wave accumulators per coefficient in LDS (32 B per real column, 64 B per complex one):
+    // a column set beyond kDotsMaxAcc accumulators is swept in chunks of the combined list (basis columns, then
+    // orthogonalizing vectors), each chunk writing its partials at its own offset; every h_c is an independent sum,
+    // so chunking does not touch the results
+    const int chunk = kDotsMaxAcc / b->es;
+    for (int c0 = 0; c0 < ncols; c0 += chunk) {
+      const int nc = std::min(chunk, ncols - c0);
+      const int v0 = std::min(c0, count), v1 = std::min(c0 + nc, count);
+      const int q0 = std::max(c0 - count, 0), q1 = std::max(c0 + nc - count, 0);
+      ProfScope ps(c, EIGENEX_K_DOTS, use_ctrl == 2 ? 0.0 : 8.0 * s.nd * nc + 8.0 * s.nd);  // a conditional pass books no bytes
+      launch_dots(c->stream, vec_ptr(s, b->cap, b->nq, src_ref), tt, colset(s, first + v0 * stride, stride, v1 - v0, qfirst + q0, q1 - q0),
+                  s.nd, s.partials + (int64_t)c0 * b->es * s.pstride, s.pstride, s.g_vec, ctl, b->es == 2);
+      LAUNCHCHK("k_dots");
     }
     ProfScope ps(c, EIGENEX_K_SMALL, 0.0);
     launch_reduce(c->stream, s.partials, s.pstride, s.g_vec, ncols * b->es, s.hbuf + base + slot * b->es, ctl);
@@ -745,6 +764,7 @@ int enq_update(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_term, in
       launch_update(c->stream, vec_ptr(s, b->cap, b->nq, src_ref), vec_ptr(s, b->cap, b->nq, dst_ref), tt,
                     colset(s, first, stride, count, qfirst, nq), s.hbuf + base + slot * b->es, s.nd, s.partials, s.g_vec, ctl,
                     b->es == 2);
+      LAUNCHCHK("k_update");
     }
     if (want_norm) {
       ProfScope ps(c, EIGENEX_K_SMALL, 0.0);
@@ -1330,6 +1350,11 @@ static int csr_upload_impl(eigenex_context_t c, int64_t n_global, int64_t row_be
   partition(n_global, c->P, c->local.back(), &lb, &le);
   if (row_begin != fb || row_begin + n_rows != le)
     return fail(EIGENEX_ERR_ARG, "rows passed do not match eigenex_partition for this context");
+  // the row pointers index col/val here on the host and in the kernels on the device: a decreasing or negative
+  // one would be an out-of-bounds access in both places (the device-resident path checks the same with k_check_csr)
+  if (rowptr[0] < 0) return fail(EIGENEX_ERR_ARG, "row pointers must be non-negative");
+  for (int64_t i = 0; i < n_rows; ++i)
+    if (rowptr[i + 1] < rowptr[i]) return fail(EIGENEX_ERR_ARG, "row pointers are not non-decreasing");
   auto* m = new eigenex_csr_s();
   m->ctx = c;
   m->n_global = n_global;

@@ -378,6 +378,12 @@ class LanczosBase {
   // roughly half a millisecond.  Device operators only: a host callback would observe the extra invocations.
   void setSpeculationBound(Index bound) { speculationBound_ = bound; }
   void setSpeculativeLookahead(bool on) { speculationOn_ = on; }
+  // fixed lookahead depth (steps computed beyond the one asked for) instead of the adaptive one; 0 = adaptive.
+  // With several ranks pass the same value on every rank.
+  void setSpeculationDepth(Index depth) { fixedDepth_ = depth < 0 ? 0 : depth; }
+  Index speculationDepth() const { return fixedDepth_; }
+  // what the next enqueue would use (for tests): depends only on settings and, on ONE rank, on the measured step time
+  Index currentLookaheadLimit() const { return lookaheadLimit_(); }
   bool speculativeLookahead() const { return speculationOn_; }
 
   // Extension: run `ncalls` calls of updateLanczosSteps() on the GPU back to back with a
@@ -467,7 +473,14 @@ class LanczosBase {
 
   // adaptive limit of steps computed beyond the one asked for (see setSpeculationBound)
   Index lookaheadLimit_() const {
-    if (!speculationOn_ || !deviceOperator_ || secondsPerCall_ <= 0.0) return 1;
+    if (!speculationOn_ || !deviceOperator_) return 1;
+    // Ranks of one job must enqueue the SAME number of step calls: every call carries collectives (all-reduces, halo
+    // send/recv), and a rank that ran further ahead than its peers would wait for partners that never come.  A depth
+    // derived from this process's own clock differs between ranks, so with more than one rank the lookahead is off
+    // unless the caller fixes a depth that is the same everywhere (setSpeculationDepth).
+    if (fixedDepth_ > 0) return fixedDepth_;
+    if (context_ && context_->worldSize() > 1) return 1;
+    if (secondsPerCall_ <= 0.0) return 1;
     return secondsPerCall_ >= 2.0e-3 ? 1 : secondsPerCall_ >= 5.0e-4 ? 2 : secondsPerCall_ >= 1.0e-4 ? 4 : 8;
   }
   Index speculativeCalls_() const {
@@ -573,6 +586,7 @@ class LanczosBase {
   bool speculationOn_ = true;
   Index speculationBound_ = 1;
   double secondsPerCall_ = 0.0;
+  Index fixedDepth_ = 0;
 };
 
 // ---------------------------------------------------------------------------
@@ -672,6 +686,11 @@ class LanczosEigenSolver {
   // Extension: see LanczosBase::setSpeculationBound (default on; results do not depend on it)
   LanczosEigenSolver& setSpeculativeLookahead(bool on) {
     lanczosBase_.setSpeculativeLookahead(on);
+    return *this;
+  }
+  // fixed lookahead depth, the same on every rank of a multi-rank job (0 = adaptive on one rank, off on several)
+  LanczosEigenSolver& setSpeculationDepth(Index depth) {
+    lanczosBase_.setSpeculationDepth(depth);
     return *this;
   }
   LanczosEigenSolver& setOrthogonalization(Orthogonalization o) {

@@ -255,3 +255,22 @@ def test_host_logic_under_sanitizers(built, tmp_path):
     out = subprocess.run([exe], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     assert b"all checks passed" in out.stdout
+
+
+def test_lookahead_depth_is_rank_invariant(tmp_path):
+    """the speculative lookahead of LanczosBase / ArnoldiBase took its depth from each process's own
+    clock; with collectives inside every step call, ranks that enqueue different numbers of calls hang.  The header-only
+    classes are linked against a recording test double of the C ABI (tests/cpp/lookahead_rank_invariance.cpp, no GPU):
+    two ranks of one job with devices of different speed must enqueue identical batch sequences."""
+    import shutil
+    import subprocess
+
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    exe = str(tmp_path / "lookahead")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-g", "-Wall", "-I", os.path.join(ROOT, "include"), "-I",
+                           os.path.join(ROOT, "cmpt-eigenex_amd", "include"),
+                           os.path.join(ROOT, "tests", "cpp", "lookahead_rank_invariance.cpp"), "-o", exe, "-lpthread"])
+    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert out.returncode == 0, (out.stdout + out.stderr).decode()[-2000:]
+    assert b"all checks passed" in out.stdout

@@ -108,3 +108,70 @@ def test_two_contexts_driven_from_two_threads(mods):
         assert not isinstance(threaded[n], Exception), threaded[n]
         np.testing.assert_array_equal(threaded[n][0], serial[n][0])
         np.testing.assert_array_equal(threaded[n][1], serial[n][1])
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_basis_wider_than_one_dots_launch(mods, cplx):
+    """k_dots keeps its per-wave accumulators in LDS (32 B per real column, 64 B per complex one), so one launch takes
+    at most 2048 real / 1024 complex columns; the reference's maxIterations is unlimited by default and the slab
+    doubles, so longer runs must be swept in chunks (such a launch used to fail silently and the update
+    subtracted stale coefficients).  A run past that limit on a small system: basis still orthonormal to rounding,
+    alpha/beta follow the oracle, the stand-alone dots primitive returns all columns, extremal Ritz values are
+    eigenvalues of the matrix."""
+    capi, _ = mods
+    from oracle import cref
+
+    rng = np.random.default_rng(77)
+    N = 1500 if cplx else 2600
+    m = 1100 if cplx else 2150  # m+1 basis columns: beyond 1024 complex / 2048 real
+    A = sp.random(N, N, density=8.0 / N, random_state=5, format="csr")
+    if cplx:
+        A = A + 1j * sp.random(N, N, density=8.0 / N, random_state=6, format="csr")
+    A = (A + A.conj().T + sp.diags(np.linspace(-3.0, 3.0, N))).tocsr()
+    A.sort_indices()
+    init = rng.standard_normal(N) + (1j * rng.standard_normal(N) if cplx else 0.0)
+    ctx = capi.Context()
+    M = capi.Csr.upload(ctx, N, A.indptr, A.indices, A.data)
+    b = capi.Basis(ctx, M, N, m + 1)
+    b.upload(capi.VEC_W, init)
+    b.lanczos_enqueue(m + 1)
+    st, alpha, beta = b.lanczos_state()
+    assert (st.nvec, st.iterations, st.stopped) == (m + 1, m, 0)
+    # orthonormality through the chunked dots primitive: column c against all m+1 columns in one call
+    worst = 0.0
+    for c in (0, 1, m // 2, m - 1, m):
+        g = b.dots(capi.VEC_COL(c), 0, 1, m + 1)
+        assert g.size == m + 1
+        g[c] -= 1.0
+        worst = max(worst, np.abs(g).max())
+    assert worst < 1e-11, worst
+    if not cplx:
+        ref = cref.CLanczos(A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data, init, cap=62)
+        assert ref.run(61) == 61
+        np.testing.assert_allclose(alpha[:61], ref.alpha, rtol=0, atol=1e-11)
+        np.testing.assert_allclose(beta[:60], ref.beta, rtol=0, atol=1e-11)
+    th = ko.tridiagonal_eigh(alpha, beta, vectors=False)[0]
+    lam = np.linalg.eigvalsh(A.toarray())
+    np.testing.assert_allclose(th[:3], lam[:3], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(th[-3:], lam[-3:], rtol=0, atol=1e-10)
+    ctx.close()
+
+
+def test_malformed_row_pointers_are_rejected_on_the_host(mods):
+    """eigenex_csr_upload indexes col/val with the caller's row pointers on the host and the kernels do so on the
+    device: decreasing or negative row pointers must come back as an argument error, not as a fault (the
+    device-resident path checks the same with k_check_csr)."""
+    capi, _ = mods
+    ctx = capi.Context()
+    col = np.array([0, 1, 2, 0, 1, 2], np.int32)
+    val = np.ones(6)
+    for bad in ([0, 4, 2, 6], [-1, 2, 4, 6], [0, 2, 7, 6]):
+        with pytest.raises(capi.EigenexError, match="row pointers"):
+            capi.Csr.upload(ctx, 3, bad, col, val)
+    for shards in (2, 3):
+        lctx = capi.Context(loopback_shards=shards)
+        with pytest.raises(capi.EigenexError, match="row pointers"):
+            capi.Csr.upload(lctx, 3, [0, 4, 2, 6], col, val)
+        lctx.close()
+    capi.Csr.upload(ctx, 3, [0, 2, 4, 6], col, val).close()
+    ctx.close()
