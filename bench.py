@@ -5,9 +5,14 @@ GB/s, 3-D Laplacian N=10^8, fp64, 1/2/4/8 GPUs").
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
+Called plainly with --gpus N > 1 (no launcher, WORLD_SIZE unset) it starts its own N rank processes -- one per GPU,
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set -- BEFORE anything touches the GPU, waits for
+them and exits with their status; rank 0 prints the JSON line.
+
 Workload (all N): 7-point Laplacian on a 512^3 grid (N = 134,217,728 rows, nnz = 937,951,232,
 CSR int32/fp64, generated on the device), Lanczos with full re-orthogonalisation,
-minIterations = maxIterations = 100 (101 basis vectors), start vector N(0,1) seeded, row-sharded
+minIterations = maxIterations = 100 (101 basis vectors), the reference's default start vector
+(std::mt19937 default seed, N(0,1), normalised: lanczos.hpp:214-218), row-sharded
 1-D over the ranks (strong scaling), one process per GPU, RCCL all-reduce + neighbour halo exchange.
 One "step" = one complete solve through LanczosEigenSolver<double>::compute() (the header-only
 C++ class with the reference's API); value = Krylov iterations per second over the timed steps.
@@ -16,17 +21,19 @@ The JSON line also carries
   roofline      HIP-event timing (on the library's stream) of the dominant kernel over the timed
                 region: algorithmic bytes (SURVEY 8d / DESIGN.md) / duration vs the 8 TB/s HBM peak
   cpu_baseline  the CPU oracle (oracle/krylov_ref.c, a port of the reference's step function)
-                timed on this host on a bounded sample (rank 0, N=1 only)
+                timed on this host on a bounded sample (rank 0, N=1 only): the first iterations of the
+                SAME 512^3 input when the host has the memory for it, else a 256^3 grid
+  multi_gpu     (N > 1) what the RCCL communicator reports, per-rank kernel times, collectives, halo bytes
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -40,23 +47,7 @@ def lanczos_bytes(n_rows: int, nnz: int, m: int) -> float:
     return m * (12.0 * nnz + 4.0 * (n_rows + 1) + 112.0 * n_rows) + 16.0 * n_rows * m * (m + 1) / 2.0
 
 
-def cpu_baseline(sample_n: int, sample_m: int, threads: int):
-    """Times the oracle's C restatement of updateLanczosSteps on a bounded sample."""
-    from oracle import cref
-
-    N = sample_n ** 3
-    rowptr, col, val = cref.laplacian3d(sample_n)
-    init = np.random.default_rng(0).standard_normal(N)
-    c = cref.CLanczos(rowptr, col, val, init, cap=sample_m + 2, nthreads=threads)
-    t0 = time.perf_counter()
-    ok = c.run(sample_m + 1)
-    dt = time.perf_counter() - t0
-    assert ok == sample_m + 1
-    by = lanczos_bytes(N, int(rowptr[-1]), sample_m)
-    return {"it_per_s": sample_m / dt, "gbs": by / dt / 1e9, "seconds": dt, "bytes_per_iteration": by / sample_m}
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -67,16 +58,181 @@ def main():
     ap.add_argument("--krylov-steps", "--m", dest="m", type=int, default=100, help="Lanczos iterations per solve")
     ap.add_argument("--sequential", action="store_true", help="reference-order sequential Gram-Schmidt instead of batched")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--seeded-start", action="store_true", help="numpy-seeded N(0,1) start vector instead of the reference default")
+    # launcher self-test (CPU, tests/test_bench_launcher.py): every rank reports its environment and exits before
+    # anything touches a GPU; --launch-check-fail R makes rank R exit with status 3 while its peers would wait
+    ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--launch-check-fail", type=int, default=-1, help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` with no launcher around it
+# ---------------------------------------------------------------------------------------------------------------------
+def visible_gpus_without_touching_them():
+    """Number of GPUs a rank process would see, counted by a short-lived child (hipGetDeviceCount through the
+    library's own entry point); None when that cannot be done.  The parent itself must not initialise HIP: it only
+    starts the ranks."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from cmpt_eigenex_amd import capi\n"
+            "print('GPUS', capi.device_count())" % ROOT)
+    try:
+        out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300)
+        for line in out.stdout.decode().splitlines():
+            if line.startswith("GPUS "):
+                return int(line.split()[1])
+    except (OSError, ValueError, subprocess.TimeoutExpired):
+        pass
+    return None
+
+
+def launch_ranks(nranks: int, argv) -> int:
+    have = visible_gpus_without_touching_them()
+    if "--launch-check" in argv:
+        have = None
+    if have is not None and have < nranks:
+        print(f"bench.py: --gpus {nranks} needs {nranks} GPUs, this machine shows {have}", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(nranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), LOCAL_WORLD_SIZE=str(nranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", BENCH_SELF_LAUNCHED="1")
+        # rank 0 owns stdout (the JSON line); every rank keeps stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    alive = set(range(nranks))
+    deadline = None
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"bench.py: rank {r} exited with status {code}; stopping the other ranks", file=sys.stderr)
+                deadline = time.monotonic() + float(os.environ.get("BENCH_LAUNCH_GRACE", "20"))  # peers blocked in a collective would wait for ever
+        if deadline is not None and time.monotonic() > deadline:
+            for r in sorted(alive):
+                procs[r].kill()  # exactly the processes started above
+            for r in sorted(alive):
+                procs[r].wait()
+            alive.clear()
+        time.sleep(0.05)
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def host_memory_available_gb() -> float:
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                gb = int(line.split()[1]) / 1e6
+                break
+        else:
+            return 0.0
+    except OSError:
+        return 0.0
+    try:  # a container's own limit may be lower
+        lim = open("/sys/fs/cgroup/memory.max").read().strip()
+        if lim != "max":
+            cur = int(open("/sys/fs/cgroup/memory.current").read())
+            gb = min(gb, (int(lim) - cur) / 1e9)
+    except (OSError, ValueError):
+        pass
+    return gb
+
+
+def host_cores() -> int:
+    from oracle import cref
+
+    try:
+        cores = min(cref.max_threads(), len(os.sched_getaffinity(0)))
+    except AttributeError:
+        cores = cref.max_threads()
+    try:  # a container's CPU share (cgroup v2 quota) is often far below the host's core count
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
+def cpu_baseline(n: int, m: int, init, N_workload: int, nnz_workload: int, m_workload: int):
+    """Times the oracle's C restatement of updateLanczosSteps (oracle/krylov_ref.c: sequential modified Gram-Schmidt,
+    CSR operator) for the first iterations of the workload: 1 thread, as the reference has no threading, and all cores
+    with OpenMP.  The checker is the thing measured here, never the product."""
+    import numpy as np
+
+    from oracle import cref
+
+    cores = host_cores()
+    need_gb = (12.0 * 7 + 4) * n ** 3 / 1e9 * 2.0 + 8.0 * n ** 3 * 15 / 1e9  # CSR (built with a transient copy) + 15 vectors
+    sample_n, sample_m = n, 10
+    note = f"the first {sample_m} iterations of the workload itself ({n}^3 Laplacian, the bench's start vector)"
+    if host_memory_available_gb() < need_gb + 8.0:
+        sample_n, sample_m = min(n, 256), 8
+        note = (f"{sample_n}^3 Laplacian, first {sample_m} iterations (host memory short of the {need_gb:.0f} GB that "
+                f"{sample_m + 2} vectors + CSR of {n}^3 need)")
+    Ns = sample_n ** 3
+    rowptr, col, val = cref.laplacian3d(sample_n)
+    x0 = init if sample_n == n else np.random.default_rng(0).standard_normal(Ns)
+
+    def run(threads, iters):
+        c = cref.CLanczos(rowptr, col, val, x0, cap=iters + 2, nthreads=threads)
+        t0 = time.perf_counter()
+        ok = c.run(iters + 1)
+        dt = time.perf_counter() - t0
+        assert ok == iters + 1
+        by = lanczos_bytes(Ns, int(rowptr[-1]), iters)
+        return {"it_per_s": iters / dt, "gbs": by / dt / 1e9, "seconds": dt, "alpha": c.alpha, "beta": c.beta}
+
+    one = run(1, sample_m)
+    allc = run(cores, sample_m)
+    per_it = lanczos_bytes(N_workload, nnz_workload, m_workload) / m_workload
+    out = {
+        "value": one["it_per_s"],
+        "unit": "iterations/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"oracle/krylov_ref.c (port of updateLanczosSteps, sequential MGS, CSR operator), {note}, "
+                  f"1 thread as in the reference; iterations/s of THOSE iterations (j <= {sample_m} basis vectors, cheaper "
+                  f"than the average step of a full m={m_workload} solve: see scaled_to_workload_it_per_s)",
+        "seconds": one["seconds"],
+        "algorithmic_gbs": one["gbs"],
+        "scaled_to_workload_it_per_s": one["gbs"] * 1e9 / per_it,
+        "all_cores": {"value": allc["it_per_s"], "cores": cores, "algorithmic_gbs": allc["gbs"], "seconds": allc["seconds"],
+                      "sample": f"same sample, OpenMP {cores} threads",
+                      "scaled_to_workload_it_per_s": allc["gbs"] * 1e9 / per_it},
+    }
+    return out, one if sample_n == n else None
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.launch_check:
+        if rank == args.launch_check_fail:
+            sys.exit(3)
+        if args.launch_check_fail >= 0:
+            time.sleep(120)  # a peer stuck in a collective whose partner died
+        print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}), flush=True)
+        return
     if world != args.gpus:
-        if args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs one process per GPU: launch with torch.distributed.run "
-                     f"--nproc-per-node {args.gpus} (WORLD_SIZE is {world})")
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch with --nproc-per-node {args.gpus}, or call "
+                 f"bench.py without a launcher and let it start its own ranks")
 
+    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -84,10 +240,18 @@ def main():
 
     if not torch.cuda.is_available() or capi.device_count() < 1:
         sys.exit("bench.py needs an MI355X: the Krylov hot path has no CPU fallback")
-    # one GPU per rank; if the launcher narrowed the visible devices per rank (HIP_VISIBLE_DEVICES), local_rank may
-    # exceed what this process can see
+    # one GPU per rank.  A launcher may have narrowed the visible devices to one per rank (HIP_VISIBLE_DEVICES): then
+    # every rank sees a single device 0.  Two ranks on one device are refused (RCCL would reject the duplicate later).
     ndev = capi.device_count()
-    dev_index = local_rank if local_rank < ndev else local_rank % ndev
+    narrowed = (any(os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+                and not os.environ.get("BENCH_SELF_LAUNCHED"))  # our own ranks all inherit one and the same device list
+    if local_rank < ndev:
+        dev_index = local_rank
+    elif narrowed and ndev == 1:
+        dev_index = 0
+    else:
+        sys.exit(f"rank {rank}: needs GPU index {local_rank} but this process sees {ndev} device(s): "
+                 f"--gpus {args.gpus} needs {args.gpus} GPUs on this node")
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
 
@@ -112,9 +276,10 @@ def main():
     if world > 1 and not ctx.rccl_selftest():
         sys.exit(f"rank {rank}: RCCL self-test (all-reduce / all-gather / send-recv ring) returned wrong data")
     A = capi.Csr.laplacian3d(ctx, n)
-    # same global start vector on every rank (seeded N(0,1)), as in the reference API where
-    # initialVector has matrixHeight entries; each rank uploads its own rows once, before the timed region
-    init = np.random.default_rng(20240601).standard_normal(N)
+    # same global start vector on every rank, as in the reference API where initialVector has matrixHeight entries:
+    # the reference's default (std::mt19937 default seed, std::normal_distribution, normalised; lanczos.hpp:214-218,
+    # random.hpp:89-101) from the host STL; each rank uploads its own rows once, before the timed region
+    init = np.random.default_rng(20240601).standard_normal(N) if args.seeded_start else solver.default_start_vector(N)
 
     es = solver.LanczosEigenSolver()
     es.setDeviceOperator(A).set(minIterations=m, maxIterations=m, computeEigenvectorsOn=0, initialVector=init,
@@ -139,11 +304,6 @@ def main():
     dt = time.perf_counter() - t0
     ctx.profile_enable(False)
 
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-
     r = es.results()
     assert r["iterations"] == m and r["nvec"] == m + 1, (r["iterations"], r["nvec"])
     nnz_global = 7 * N - 6 * n * n
@@ -152,16 +312,52 @@ def main():
     kinds = {"spmv": capi.K_SPMV, "dots": capi.K_DOTS, "update": capi.K_UPDATE, "small": capi.K_SMALL, "comm": capi.K_COMM}
     prof = {k: ctx.profile_get(v) for k, v in kinds.items()}
     kernel_names = {"spmv": "k_spmv", "dots": "k_dots", "update": "k_update"}
+
+    multi = None
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        # per-rank view: what the communicator itself says, kernel and collective times, halo volume
+        ranks, crank, cdev = ctx.comm_info()
+        info = A.info()
+        mine = torch.tensor([ranks, crank, cdev, info["n_local"], info["n_halo_local"]] +
+                            [prof[k][1] for k in ("spmv", "dots", "update", "small", "comm")] +
+                            [prof["update"][0], prof["comm"][0]], dtype=torch.float64, device=dev)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        tab = np.array([v.cpu().numpy() for v in allv])
+        per_launch_update = tab[:, 7] / np.maximum(tab[:, 10], 1)
+        multi = {
+            "rccl_ranks": int(tab[0, 0]),
+            "rccl_rank_of_each_process": [int(x) for x in tab[:, 1]],
+            "device_of_each_rank": [int(x) for x in tab[:, 2]],
+            "rows_per_rank": [int(x) for x in tab[:, 3]],
+            "halo_bytes_per_step_per_rank": [int(x) * 8 for x in tab[:, 4]],
+            "halo_bytes_per_step_total": int(tab[:, 4].sum()) * 8,
+            "k_update_avg_launch_ms_min": float(per_launch_update.min()),
+            "k_update_avg_launch_ms_max": float(per_launch_update.max()),
+            "kernel_ms_per_rank": {k: [float(x) for x in tab[:, 5 + i]] for i, k in enumerate(("k_spmv", "k_dots", "k_update", "small", "comm"))},
+            "comm_launches_per_rank": [int(x) for x in tab[:, 11]],
+            "comm_ms_per_step_max": float(tab[:, 9].max()) / args.steps,
+            "comm_launches_per_iteration": float(tab[:, 11].max()) / (args.steps * m),  # all-reduces + halo exchange (counted by the library)
+        }
+        assert multi["rccl_ranks"] == world, multi
+
     dom = max(kernel_names, key=lambda k: prof[k][1])
     cnt, ms, by = prof[dom]
     achieved = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    traffic = None
+    # HBM bytes per launch from the PMC passes (rocprofv3 cannot run inside this process): the committed summary of the
+    # passes over this same command, profiles/hbm_traffic.json (scripts/summarize_rocprof.py), with its provenance
+    traffic = traffic_src = None
     tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tfile):
         try:
             t = json.load(open(tfile))
             key = f"laplacian3d_{n}_m{m}_gpus{world}"
             traffic = t.get(key, {}).get(kernel_names[dom], {}).get("bytes_per_launch")
+            if traffic is not None:
+                traffic_src = f"profiles/hbm_traffic.json[{key}] ({t.get(key, {}).get('__source__', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes')})"
         except Exception:
             traffic = None
 
@@ -184,6 +380,8 @@ def main():
                             f"full re-orthogonalisation ({'sequential' if args.sequential else 'batched'} Gram-Schmidt), "
                             f"row-sharded over {world} GPU(s)",
                 "step": "one LanczosEigenSolver<double>::compute() of m iterations (m+1 basis vectors), eigenvalues only",
+                "start_vector": "numpy default_rng(20240601) N(0,1)" if args.seeded_start else
+                                "reference default: std::mt19937() + std::normal_distribution, normalised (lanczos.hpp:214-218)",
                 "parallelism": f"rows{world}",
                 "n": n, "m": m,
             },
@@ -197,6 +395,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": traffic_src,
                 "launches": cnt,
                 "avg_launch_ms": ms / cnt if cnt else None,
                 "algorithmic_bytes_per_launch": by / cnt if cnt else None,
@@ -205,36 +404,17 @@ def main():
                                for k in prof},
             },
         }
+        if multi is not None:
+            out["multi_gpu"] = multi
         if world == 1 and not args.no_cpu_baseline:
-            from oracle import cref
-
-            try:
-                cores = min(cref.max_threads(), len(os.sched_getaffinity(0)))
-            except AttributeError:
-                cores = cref.max_threads()
-            try:  # a container's CPU share (cgroup v2 quota) is often far below the host's core count
-                quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-                if quota != "max":
-                    cores = max(1, min(cores, int(int(quota) / int(period))))
-            except (OSError, ValueError):
-                pass
-            sn, sm = 256, 8  # 11 vectors x 134 MB + 1.4 GB CSR: well beyond the host's last-level cache
-            one = cpu_baseline(sn, sm, 1)
-            allc = cpu_baseline(256, 16, cores)
-            per_it = lanczos_bytes(N, nnz_global, m) / m
-            out["cpu_baseline"] = {
-                "value": one["it_per_s"],
-                "unit": "iterations/s",
-                "cores": 1,
-                "kind": "port",
-                "sample": f"oracle/krylov_ref.c (port of updateLanczosSteps, sequential MGS, CSR operator), "
-                          f"{sn}^3 Laplacian, first {sm} iterations, 1 thread as in the reference",
-                "algorithmic_gbs": one["gbs"],
-                "scaled_to_workload_it_per_s": one["gbs"] * 1e9 / per_it,
-                "all_cores": {"value": allc["it_per_s"], "cores": cores, "algorithmic_gbs": allc["gbs"],
-                              "sample": f"256^3 Laplacian, first 16 iterations, OpenMP {cores} threads",
-                              "scaled_to_workload_it_per_s": allc["gbs"] * 1e9 / per_it},
-            }
+            cb, same_input = cpu_baseline(n, m, init, N, nnz_global, m)
+            if same_input is not None:
+                # the same input on both sides: the oracle's coefficients next to the device's (a check, not a number)
+                k = len(same_input["alpha"])
+                cb["max_abs_alpha_beta_difference_vs_device"] = float(max(
+                    np.abs(np.asarray(r["alpha"][:k]) - same_input["alpha"]).max(),
+                    np.abs(np.asarray(r["beta"][:k - 1]) - same_input["beta"][:k - 1]).max()))
+            out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
 
     es.close()

@@ -64,6 +64,7 @@ SIGNATURES = {
     "eigenex_context_selftest": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "eigenex_context_sync": (C.c_int, [_vp]),
     "eigenex_context_info": (C.c_int, [_vp] + [C.POINTER(C.c_int)] * 4),
+    "eigenex_context_comm_info": (C.c_int, [_vp] + [C.POINTER(C.c_int)] * 3),
     "eigenex_context_stream": (_vp, [_vp]),
     "eigenex_profile_enable": (C.c_int, [_vp, C.c_int]),
     "eigenex_profile_reset": (C.c_int, [_vp]),
@@ -100,6 +101,7 @@ SIGNATURES = {
     "eigenex_axpy2": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int]),
     "eigenex_scale": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double]),
     "eigenex_lanczos_enqueue": (C.c_int, [_vp, C.c_int]),
+    "eigenex_basis_set_alpha_fusion": (C.c_int, [_vp, C.c_int]),
     "eigenex_arnoldi_enqueue": (C.c_int, [_vp, C.c_int]),
     "eigenex_lanczos_restart": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double]),
     "eigenex_lanczos_state": (C.c_int, [_vp, C.POINTER(State), _dp, _dp]),
@@ -200,6 +202,12 @@ class Context:
         v = [C.c_int() for _ in range(4)]
         _chk(lib().eigenex_context_info(self.h, *[C.byref(x) for x in v]))
         return dict(zip(("rank", "world_size", "nshards_total", "nshards_local"), (x.value for x in v)))
+
+    def comm_info(self):
+        """(ranks, rank, device) as the RCCL communicator reports them; ranks = 0 without a communicator"""
+        v = [C.c_int() for _ in range(3)]
+        _chk(lib().eigenex_context_comm_info(self.h, *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)
 
     def sync(self):
         _chk(lib().eigenex_context_sync(self.h))
@@ -385,6 +393,9 @@ class Basis:
 
     def tune(self, vec_blocks_per_cu=2, spmv_blocks_per_cu=4, flags=0):
         _chk(lib().eigenex_basis_tune(self.h, vec_blocks_per_cu, spmv_blocks_per_cu, flags))
+
+    def set_alpha_fusion(self, on: bool):
+        _chk(lib().eigenex_basis_set_alpha_fusion(self.h, int(bool(on))))
 
     def clear(self):
         _chk(lib().eigenex_basis_clear(self.h))

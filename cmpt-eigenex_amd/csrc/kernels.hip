@@ -148,37 +148,31 @@ __device__ __forceinline__ double wave_sum4(double s0, double s1, double s2, dou
   return k;
 }
 
-template <bool FULL, bool CPLX, bool RED4>
+// DUAL: a second source vector src2 (no recurrence) is dotted with the same column tiles in the same pass; its sums go
+// to wave_acc2.  Used by the fused-alpha Lanczos step (library.hip: lanczos_call), where the Gram column V^H u_k is needed
+// next to V^H v; the column tiles are loaded once for both.
+template <bool FULL, bool CPLX, bool RED4, bool DUAL>
 __device__ __forceinline__ void dots_tile(const double* __restrict__ src, const ThreeTerm& tt, double a, double b,
-                                          const ColumnSet& cs, int ncols, int64_t base, int64_t n, double* wave_acc) {
+                                          const double* __restrict__ src2, const ColumnSet& cs, int ncols, int64_t base,
+                                          int64_t n, double* wave_acc, double* wave_acc2) {
   constexpr int ES = CPLX ? 2 : 1;
   const int lane = threadIdx.x & 63;
-  double2 w[4];
+  double2 w[4], w2[4];
   load_w0<FULL>(w, src, tt, a, b, base, n);
+  if (DUAL) load_col<FULL>(w2, src2, base, n);
   // columns are visited from the last one down: with full re-orthogonalisation the first group then
   // contains u_k and u_{k-1}, whose tiles load_w0 has just pulled through L1/L2 (no second HBM read);
   // every h_c is an independent sum, so the order does not touch the results.
-  const int rem = ncols & 3;
-  for (int ci = ncols - 4; ci >= 0; ci -= 4) {
-    double2 x0[4], x1[4], x2[4], x3[4];
-    load_col<FULL>(x3, column_ptr(cs, ci + 3), base, n);
-    load_col<FULL>(x2, column_ptr(cs, ci + 2), base, n);
-    load_col<FULL>(x1, column_ptr(cs, ci + 1), base, n);
-    load_col<FULL>(x0, column_ptr(cs, ci + 0), base, n);
-    double r0, r1, r2, r3, i0, i1, i2, i3;
-    dotc8<CPLX>(w, x0, r0, i0);
-    dotc8<CPLX>(w, x1, r1, i1);
-    dotc8<CPLX>(w, x2, r2, i2);
-    dotc8<CPLX>(w, x3, r3, i3);
+  auto add4 = [&](double* acc, int ci, double r0, double r1, double r2, double r3, double i0, double i1, double i2, double i3) {
     if (RED4) {
       const double kr = wave_sum4(r0, r1, r2, r3, lane);
       double ki = 0.0;
       if (CPLX) ki = wave_sum4(i0, i1, i2, i3, lane);
       if ((lane & 15) == 0) {
-        wave_acc[ES * (ci + (lane >> 4))] += kr;
-        if (CPLX) wave_acc[ES * (ci + (lane >> 4)) + 1] += ki;
+        acc[ES * (ci + (lane >> 4))] += kr;
+        if (CPLX) acc[ES * (ci + (lane >> 4)) + 1] += ki;
       }
-      continue;
+      return;
     }
     r0 = wave_sum(r0);
     r1 = wave_sum(r1);
@@ -191,16 +185,37 @@ __device__ __forceinline__ void dots_tile(const double* __restrict__ src, const 
       i3 = wave_sum(i3);
     }
     if (lane == 0) {
-      wave_acc[ES * (ci + 0)] += r0;
-      wave_acc[ES * (ci + 1)] += r1;
-      wave_acc[ES * (ci + 2)] += r2;
-      wave_acc[ES * (ci + 3)] += r3;
+      acc[ES * (ci + 0)] += r0;
+      acc[ES * (ci + 1)] += r1;
+      acc[ES * (ci + 2)] += r2;
+      acc[ES * (ci + 3)] += r3;
       if (CPLX) {
-        wave_acc[ES * (ci + 0) + 1] += i0;
-        wave_acc[ES * (ci + 1) + 1] += i1;
-        wave_acc[ES * (ci + 2) + 1] += i2;
-        wave_acc[ES * (ci + 3) + 1] += i3;
+        acc[ES * (ci + 0) + 1] += i0;
+        acc[ES * (ci + 1) + 1] += i1;
+        acc[ES * (ci + 2) + 1] += i2;
+        acc[ES * (ci + 3) + 1] += i3;
       }
+    }
+  };
+  const int rem = ncols & 3;
+  for (int ci = ncols - 4; ci >= 0; ci -= 4) {
+    double2 x0[4], x1[4], x2[4], x3[4];
+    load_col<FULL>(x3, column_ptr(cs, ci + 3), base, n);
+    load_col<FULL>(x2, column_ptr(cs, ci + 2), base, n);
+    load_col<FULL>(x1, column_ptr(cs, ci + 1), base, n);
+    load_col<FULL>(x0, column_ptr(cs, ci + 0), base, n);
+    double r0, r1, r2, r3, i0, i1, i2, i3;
+    dotc8<CPLX>(w, x0, r0, i0);
+    dotc8<CPLX>(w, x1, r1, i1);
+    dotc8<CPLX>(w, x2, r2, i2);
+    dotc8<CPLX>(w, x3, r3, i3);
+    add4(wave_acc, ci, r0, r1, r2, r3, i0, i1, i2, i3);
+    if (DUAL) {
+      dotc8<CPLX>(w2, x0, r0, i0);
+      dotc8<CPLX>(w2, x1, r1, i1);
+      dotc8<CPLX>(w2, x2, r2, i2);
+      dotc8<CPLX>(w2, x3, r3, i3);
+      add4(wave_acc2, ci, r0, r1, r2, r3, i0, i1, i2, i3);
     }
   }
   for (int ci = rem - 1; ci >= 0; --ci) {
@@ -214,35 +229,50 @@ __device__ __forceinline__ void dots_tile(const double* __restrict__ src, const 
       wave_acc[ES * ci] += r0;
       if (CPLX) wave_acc[ES * ci + 1] += i0;
     }
+    if (DUAL) {
+      dotc8<CPLX>(w2, x0, r0, i0);
+      r0 = wave_sum(r0);
+      if (CPLX) i0 = wave_sum(i0);
+      if (lane == 0) {
+        wave_acc2[ES * ci] += r0;
+        if (CPLX) wave_acc2[ES * ci + 1] += i0;
+      }
+    }
   }
 }
 
-// partials[(ES*c + part)*pstride + block]
-template <bool CPLX, bool RED4>
-__global__ __launch_bounds__(kBlock) void k_dots(const double* __restrict__ src, ThreeTerm tt, ColumnSet cs,
-                                                 int64_t n, int64_t ntiles, double* __restrict__ partials,
-                                                 int pstride, const Ctrl* __restrict__ ctrl) {
-  extern __shared__ double lds[];  // [4 waves][ES*ncols]
+// partials[(ES*c + part)*pstride + block]; DUAL: the second source's sums in partials2, same layout
+template <bool CPLX, bool RED4, bool DUAL>
+__global__ __launch_bounds__(kBlock) void k_dots(const double* __restrict__ src, ThreeTerm tt, const double* __restrict__ src2,
+                                                 ColumnSet cs, int64_t n, int64_t ntiles, double* __restrict__ partials,
+                                                 double* __restrict__ partials2, int pstride, const Ctrl* __restrict__ ctrl) {
+  extern __shared__ double lds[];  // [DUAL ? 2 : 1][4 waves][ES*ncols]
   if (ctrl->stopped) return;
   constexpr int ES = CPLX ? 2 : 1;
   const int ncols = cs.count + cs.nq;
   const int nacc = ES * ncols;
   const int wave = threadIdx.x >> 6;
-  for (int i = threadIdx.x; i < 4 * nacc; i += kBlock) lds[i] = 0.0;
+  for (int i = threadIdx.x; i < (DUAL ? 8 : 4) * nacc; i += kBlock) lds[i] = 0.0;
   __syncthreads();
   const double a = tt.uk ? *tt.a : 0.0;
   const double b = (tt.uk && tt.ukm1) ? *tt.b : 0.0;
   double* wave_acc = lds + wave * nacc;
+  double* wave_acc2 = lds + (4 + wave) * nacc;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t base = tile * kTileRows + 2 * threadIdx.x;
     if ((tile + 1) * kTileRows <= n)
-      dots_tile<true, CPLX, RED4>(src, tt, a, b, cs, ncols, base, n, wave_acc);
+      dots_tile<true, CPLX, RED4, DUAL>(src, tt, a, b, src2, cs, ncols, base, n, wave_acc, wave_acc2);
     else
-      dots_tile<false, CPLX, RED4>(src, tt, a, b, cs, ncols, base, n, wave_acc);
+      dots_tile<false, CPLX, RED4, DUAL>(src, tt, a, b, src2, cs, ncols, base, n, wave_acc, wave_acc2);
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < nacc; c += kBlock)
+  for (int c = threadIdx.x; c < nacc; c += kBlock) {
     partials[(int64_t)c * pstride + blockIdx.x] = (lds[c] + lds[nacc + c]) + (lds[2 * nacc + c] + lds[3 * nacc + c]);
+    if (DUAL) {
+      const double* l2 = lds + 4 * nacc;
+      partials2[(int64_t)c * pstride + blockIdx.x] = (l2[c] + l2[nacc + c]) + (l2[2 * nacc + c] + l2[3 * nacc + c]);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -864,6 +894,20 @@ __global__ void k_fin_alpha(Ctrl* ctrl, const double* val, double* alpha, int fi
   fin_alpha_apply(ctrl, *val, alpha, first);
 }
 
+// Fused-alpha Lanczos step (library.hip: lanczos_call): fused = all-reduced [alpha_k (2 slots), g = V^H (v - beta u_{k-1})
+// (ncoef doubles), G = V^H u_k (ncoef doubles)].  h = g - alpha_k G = V^H (v - alpha_k u_k - beta u_{k-1}) up to rounding
+// (alpha, beta real: the same formula on every double, complex or not), and alpha_k joins the series exactly as
+// k_fin_alpha would have done after the operator (lanczos.hpp:395, :448-450).
+__global__ __launch_bounds__(kBlock) void k_form_h(Ctrl* ctrl, const double* __restrict__ fused, int ncoef, double* __restrict__ h,
+                                                   double* alpha, int first) {
+  if (ctrl->stopped) return;
+  const double a = fused[0];
+  const double* g = fused + 2;
+  const double* G = g + ncoef;
+  for (int i = threadIdx.x; i < ncoef; i += kBlock) h[i] = fma(-a, G[i], g[i]);
+  if (threadIdx.x == 0) fin_alpha_apply(ctrl, a, alpha, first);
+}
+
 __global__ void k_arnoldi_begin(Ctrl* ctrl, double threshold, int64_t n_global, int cap, double* H, int ldh, int es) {
   if (threadIdx.x != 0 || ctrl->stopped) return;
   const int k = ctrl->nvec;
@@ -1186,26 +1230,34 @@ int grid_for_tiles(int64_t ntiles, int blocks_per_cu) {
 void set_num_cu(int n) { g_num_cu = n > 0 ? n : 256; }
 
 void launch_dots(hipStream_t s, const double* src, ThreeTerm tt, ColumnSet cs, int64_t n, double* partials,
-                 int pstride, int grid, const Ctrl* ctrl, bool cplx) {
+                 int pstride, int grid, const Ctrl* ctrl, bool cplx, const double* src2, double* partials2) {
   const int ncols = cs.count + cs.nq;
   if (ncols <= 0) return;
   const int64_t ntiles = (n + kTileRows - 1) / kTileRows;
-  const size_t shmem = (size_t)4 * ncols * (cplx ? 2 : 1) * sizeof(double);
+  const size_t shmem = (size_t)(src2 ? 8 : 4) * ncols * (cplx ? 2 : 1) * sizeof(double);
   static const bool red4 = [] {
     const char* e = getenv("EIGENEX_DOTS_RED4");
     return e ? atoi(e) != 0 : true;
   }();
-  if (cplx) {
-    if (red4)
-      hipLaunchKernelGGL((k_dots<true, true>), dim3(grid), dim3(kBlock), shmem, s, src, tt, cs, n, ntiles, partials, pstride, ctrl);
+#define EIGENEX_LAUNCH_DOTS(C, R, D) \
+  hipLaunchKernelGGL((k_dots<C, R, D>), dim3(grid), dim3(kBlock), shmem, s, src, tt, src2, cs, n, ntiles, partials, partials2, pstride, ctrl)
+  if (src2) {
+    if (cplx)
+      EIGENEX_LAUNCH_DOTS(true, true, true);
     else
-      hipLaunchKernelGGL((k_dots<true, false>), dim3(grid), dim3(kBlock), shmem, s, src, tt, cs, n, ntiles, partials, pstride, ctrl);
+      EIGENEX_LAUNCH_DOTS(false, true, true);
+  } else if (cplx) {
+    if (red4)
+      EIGENEX_LAUNCH_DOTS(true, true, false);
+    else
+      EIGENEX_LAUNCH_DOTS(true, false, false);
   } else {
     if (red4)
-      hipLaunchKernelGGL((k_dots<false, true>), dim3(grid), dim3(kBlock), shmem, s, src, tt, cs, n, ntiles, partials, pstride, ctrl);
+      EIGENEX_LAUNCH_DOTS(false, true, false);
     else
-      hipLaunchKernelGGL((k_dots<false, false>), dim3(grid), dim3(kBlock), shmem, s, src, tt, cs, n, ntiles, partials, pstride, ctrl);
+      EIGENEX_LAUNCH_DOTS(false, false, false);
   }
+#undef EIGENEX_LAUNCH_DOTS
 }
 
 void launch_update(hipStream_t s, const double* src, double* dst, ThreeTerm tt, ColumnSet cs, const double* h,
@@ -1294,6 +1346,10 @@ void launch_fin_norm(hipStream_t s, Ctrl* ctrl, const double* nrm2, double thres
 
 void launch_fin_alpha(hipStream_t s, Ctrl* ctrl, const double* val, double* alpha, int first, int /*cap*/) {
   hipLaunchKernelGGL(k_fin_alpha, dim3(1), dim3(64), 0, s, ctrl, val, alpha, first);
+}
+
+void launch_form_h(hipStream_t s, Ctrl* ctrl, const double* fused, int ncoef, double* h, double* alpha, int first) {
+  hipLaunchKernelGGL(k_form_h, dim3(1), dim3(kBlock), 0, s, ctrl, fused, ncoef, h, alpha, first);
 }
 
 void launch_arnoldi_begin(hipStream_t s, Ctrl* ctrl, double threshold, int64_t n_global, int cap, double* H,

@@ -48,8 +48,11 @@ void set_num_cu(int n);
 // partials[c*pstride + block], c < ncols: per-block partial dot of w0 with column c
 // Vector lengths `n` of dots/update are in DOUBLES (a complex vector of N entries = 2N interleaved doubles);
 // cplx selects conjugate-linear complex arithmetic; complex partials occupy rows 2c (re) and 2c+1 (im).
+// src2 != nullptr: the same columns are also dotted with src2 (no recurrence) in the same pass, sums in partials2
 void launch_dots(hipStream_t s, const double* src, ThreeTerm tt, ColumnSet cs, int64_t n, double* partials,
-                 int pstride, int grid, const Ctrl* ctrl, bool cplx);
+                 int pstride, int grid, const Ctrl* ctrl, bool cplx, const double* src2 = nullptr, double* partials2 = nullptr);
+// fused-alpha Lanczos step: h[i] = g[i] - alpha*G[i] from fused = [alpha, -, g (ncoef), G (ncoef)]; alpha joins the series
+void launch_form_h(hipStream_t s, Ctrl* ctrl, const double* fused, int ncoef, double* h, double* alpha, int first);
 // dst = w0 - sum_c h[c]*col_c (sequential in c); partials[block] = partial ||dst||^2
 void launch_update(hipStream_t s, const double* src, double* dst, ThreeTerm tt, ColumnSet cs, const double* h,
                    int64_t n, double* partials, int grid, const Ctrl* ctrl, bool cplx);

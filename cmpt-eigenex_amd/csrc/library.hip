@@ -48,7 +48,10 @@ int fail(int code, const std::string& msg) {
   } while (0)
 
 // a kernel launch reports a bad configuration (e.g. more dynamic LDS than a workgroup may have) only through the
-// runtime's last-error slot: without this check the launch is skipped silently and later kernels read stale data
+// runtime's last-error slot: without this check the launch is skipped silently and later kernels read stale data.
+// The slot is sticky and shared with everything else on the thread (torch's device probing leaves "invalid device
+// ordinal" behind), so LAUNCH_BEGIN() empties it right before the launch that LAUNCHCHK() then judges.
+#define LAUNCH_BEGIN() (void)hipGetLastError()
 #define LAUNCHCHK(what)                                                                                   \
   do {                                                                                                    \
     hipError_t e_ = hipGetLastError();                                                                    \
@@ -262,6 +265,11 @@ struct eigenex_basis_s {
   Ctrl* pin_ctrl = nullptr;
   std::vector<StepGraph> graphs;
   uint64_t graph_clock = 0;
+  // Lanczos on more than one shard: alpha of the newest vector travels with the next step's dots (lanczos_call)
+  bool fuse_alpha = true;
+  bool alpha_pending = false, alpha_pending_first = false;  // hbuf[base_fused()] holds a local, not yet all-reduced alpha
+  int hbuf_len() const { return 8 * maxcols + 64; }
+  int base_fused() const { return 4 * maxcols + 16; }  // [alpha (2 slots), g (es*ncols), G (es*ncols)]: one all-reduce
   // offsets (in doubles) into hbuf behind the es*maxcols coefficient entries
   int slot_nrm() const { return es * maxcols; }
   int slot_alpha() const { return es * maxcols + 1; }  // (re, im) for complex
@@ -733,6 +741,7 @@ int enq_dots(eigenex_basis_s* b, int src_ref, bool three_term, int k, int first,
       const int v0 = std::min(c0, count), v1 = std::min(c0 + nc, count);
       const int q0 = std::max(c0 - count, 0), q1 = std::max(c0 + nc - count, 0);
       ProfScope ps(c, EIGENEX_K_DOTS, use_ctrl == 2 ? 0.0 : 8.0 * s.nd * nc + 8.0 * s.nd);  // a conditional pass books no bytes
+      LAUNCH_BEGIN();
       launch_dots(c->stream, vec_ptr(s, b->cap, b->nq, src_ref), tt, colset(s, first + v0 * stride, stride, v1 - v0, qfirst + q0, q1 - q0),
                   s.nd, s.partials + (int64_t)c0 * b->es * s.pstride, s.pstride, s.g_vec, ctl, b->es == 2);
       LAUNCHCHK("k_dots");
@@ -741,6 +750,44 @@ int enq_dots(eigenex_basis_s* b, int src_ref, bool three_term, int k, int first,
     launch_reduce(c->stream, s.partials, s.pstride, s.g_vec, ncols * b->es, s.hbuf + base + slot * b->es, ctl);
   }
   return allreduce(b, base + slot * b->es, ncols * b->es);
+}
+
+// Fused-alpha Lanczos step, dots half (one collective fewer per step).  On entry hbuf[base_fused()] holds
+// this shard's partial alpha_k = u_k . v, left there by the operator of the previous call and not yet all-reduced.
+// One pass over the slab computes g = V^H (v - beta_{k-1} u_{k-1}) AND the Gram column G = V^H u_k; [alpha_k, g, G]
+// are all-reduced together, then h = g - alpha_k G = V^H w0 (w0 = v - alpha_k u_k - beta_{k-1} u_{k-1},
+// lanczos.hpp:403-408) without w0 ever needing the global alpha_k before the pass.  G is computed, not assumed to be
+// e_k: dropping the alpha_k (u_c . u_k) terms would let the loss of orthogonality grow by alpha/beta per step.
+// Afterwards hbuf[0 ..) = h and alpha[k] is set, exactly what enq_update(three_term) expects.
+int enq_fused_dots(eigenex_basis_s* b, int k, int first, int stride, int count, int nq) {
+  eigenex_context_s* c = b->ctx;
+  const int ncols = count + nq, es = b->es, ncoef = ncols * es;
+  const int off = b->base_fused();
+  for (auto& s : b->sh) {
+    ThreeTerm tt{nullptr, nullptr, nullptr, nullptr};
+    if (k > 0) tt = ThreeTerm{s.V + (int64_t)(k - 1) * s.ldd, nullptr, s.beta + (k - 1), s.beta + (k - 1)};  // v - beta_{k-1} u_{k-1}
+    const int chunk = kDotsMaxAcc / (2 * es);
+    for (int c0 = 0; c0 < ncols; c0 += chunk) {
+      const int nc = std::min(chunk, ncols - c0);
+      const int v0 = std::min(c0, count), v1 = std::min(c0 + nc, count);
+      const int q0 = std::max(c0 - count, 0), q1 = std::max(c0 + nc - count, 0);
+      ProfScope ps(c, EIGENEX_K_DOTS, 8.0 * s.nd * nc + 8.0 * s.nd);
+      LAUNCH_BEGIN();
+      launch_dots(c->stream, s.v, tt, colset(s, first + v0 * stride, stride, v1 - v0, q0, q1 - q0), s.nd,
+                  s.partials + (int64_t)c0 * es * s.pstride, s.pstride, s.g_vec, s.ctrl, es == 2, s.V + (int64_t)k * s.ldd,
+                  s.partials + (int64_t)(ncoef + c0 * es) * s.pstride);
+      LAUNCHCHK("k_dots (two sources)");
+    }
+    ProfScope ps(c, EIGENEX_K_SMALL, 0.0);
+    launch_reduce(c->stream, s.partials, s.pstride, s.g_vec, 2 * ncoef, s.hbuf + off + 2, s.ctrl);
+  }
+  CHK(allreduce(b, off, 2 + 2 * ncoef));
+  for (auto& s : b->sh) {
+    ProfScope ps(c, EIGENEX_K_SMALL, 0.0);
+    launch_form_h(c->stream, s.ctrl, s.hbuf + off, ncoef, s.hbuf, s.alpha, b->alpha_pending_first ? 1 : 0);
+  }
+  b->alpha_pending = false;
+  return 0;
 }
 
 // dst = w0(src, tt) - sum h[slot+c]*col_c ; hbuf[slot_nrm] = all-reduced ||dst||^2 (if want_norm)
@@ -761,6 +808,7 @@ int enq_update(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_term, in
     const Ctrl* ctl = pick_ctrl(s, use_ctrl);
     {
       ProfScope ps(c, EIGENEX_K_UPDATE, use_ctrl == 2 ? 0.0 : 8.0 * s.nd * ncols + 24.0 * s.nd + (three_term ? 32.0 * s.nd : 0.0));
+      LAUNCH_BEGIN();
       launch_update(c->stream, vec_ptr(s, b->cap, b->nq, src_ref), vec_ptr(s, b->cap, b->nq, dst_ref), tt,
                     colset(s, first, stride, count, qfirst, nq), s.hbuf + base + slot * b->es, s.nd, s.partials, s.g_vec, ctl,
                     b->es == 2);
@@ -786,7 +834,8 @@ int enq_update(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_term, in
 // fin_mode (a FinNormMode) names the decision the caller takes from the norm; when it can ride on the norm's second
 // stage (*fin_merged = true) the caller must not launch k_fin_norm itself
 int enq_orthogonalize(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_term, int k, int first, int stride,
-                      int count, int nq, bool q_first, bool norm_before = false, int fin_mode = -1, bool* fin_merged = nullptr) {
+                      int count, int nq, bool q_first, bool norm_before = false, int fin_mode = -1, bool* fin_merged = nullptr,
+                      bool fused_alpha = false) {
   const int merge = (fin_mode >= 0 && fin_merged && decides_locally(b)) ? fin_mode : -1;
   if (fin_merged) *fin_merged = false;
   int mode = b->ortho_mode;
@@ -825,7 +874,10 @@ int enq_orthogonalize(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_t
   }
   if (mode == EIGENEX_ORTHO_BATCHED || mode == EIGENEX_ORTHO_BATCHED_TWICE) {
     const bool twice = mode == EIGENEX_ORTHO_BATCHED_TWICE && count + nq > 0;
-    CHK(enq_dots(b, src_ref, three_term, k, first, stride, count, 0, nq, 0, true));
+    if (fused_alpha)  // Lanczos on several shards: alpha_k rides on this all-reduce (enq_fused_dots)
+      CHK(enq_fused_dots(b, k, first, stride, count, nq));
+    else
+      CHK(enq_dots(b, src_ref, three_term, k, first, stride, count, 0, nq, 0, true));
     CHK(enq_update(b, src_ref, dst_ref, three_term, k, first, stride, count, 0, nq, 0, !twice, true, 0, -1, twice ? -1 : merge));
     if (!twice) {
       if (merge >= 0) *fin_merged = true;
@@ -892,7 +944,10 @@ void launch_operator(hipStream_t st, const CsrShard* m, int es, const double* x_
 // self_norm (instead of want_dot, device operators only): hbuf[slot_nrm_before] = all-reduced ||v||^2
 // alpha_mode (a FinAlphaMode, with want_dot): as for enq_orthogonalize, *fin_merged tells the caller that k_fin_alpha
 // has been taken care of
-int enq_apply(eigenex_basis_s* b, int ucol, bool want_dot, bool self_norm = false, int alpha_mode = -1, bool* fin_merged = nullptr) {
+// defer_alpha (with want_dot, several shards): the shard's partial alpha is only summed locally into hbuf[base_fused()];
+// the all-reduce and k_fin_alpha happen with the next step's dots (enq_fused_dots)
+int enq_apply(eigenex_basis_s* b, int ucol, bool want_dot, bool self_norm = false, int alpha_mode = -1, bool* fin_merged = nullptr,
+              bool defer_alpha = false) {
   eigenex_context_s* c = b->ctx;
   const int merge = (want_dot && alpha_mode >= 0 && fin_merged && b->csr && decides_locally(b)) ? alpha_mode : -1;
   if (fin_merged) *fin_merged = merge >= 0;
@@ -921,10 +976,11 @@ int enq_apply(eigenex_basis_s* b, int ucol, bool want_dot, bool self_norm = fals
         if (merge >= 0)
           launch_reduce_fin(c->stream, s.partials, s.pstride, s.g_spmv, b->es, s.hbuf + b->slot_alpha(), s.ctrl, merge, s.alpha, 0.0);
         else
-          launch_reduce(c->stream, s.partials, s.pstride, s.g_spmv, b->es, s.hbuf + b->slot_alpha(), s.ctrl);
+          launch_reduce(c->stream, s.partials, s.pstride, s.g_spmv, b->es, s.hbuf + (defer_alpha ? b->base_fused() : b->slot_alpha()), s.ctrl);
       }
     }
     if (self_norm) return allreduce(b, b->slot_nrm_before(), 1);
+    if (want_dot && defer_alpha) return 0;
     return want_dot && merge < 0 ? allreduce(b, b->slot_alpha(), b->es) : 0;
   }
   // operator lives in host code (MatMulFunction, lanczos.hpp:116): stage through pinned memory
@@ -958,15 +1014,36 @@ int enq_initial_vector(eigenex_basis_s* b) {
   return 0;
 }
 
-// one call of LanczosBase::updateLanczosSteps()  (lanczos.hpp:371-457)
-int lanczos_call(eigenex_basis_s* b) {
+// Can the alpha of the vector a call adds stay un-reduced until the next call's dots?  Only between shards (one shard
+// merges its tiny launches instead), with a device operator and a batched scheme.
+inline bool fuses_alpha(const eigenex_basis_s* b) {
+  return b->fuse_alpha && !decides_locally(b) && b->csr && b->ortho_mode != EIGENEX_ORTHO_SEQUENTIAL;
+}
+
+// all-reduce and record an alpha that was left pending (a step without columns to orthogonalise against follows)
+int close_pending_alpha(eigenex_basis_s* b) {
+  if (!b->alpha_pending) return 0;
+  CHK(allreduce(b, b->base_fused(), b->es));
+  for (auto& s : b->sh) launch_fin_alpha(b->ctx->stream, s.ctrl, s.hbuf + b->base_fused(), s.alpha, b->alpha_pending_first ? 1 : 0, b->cap);
+  b->alpha_pending = false;
+  return 0;
+}
+
+// one call of LanczosBase::updateLanczosSteps()  (lanczos.hpp:371-457).
+// Collectives per call between shards: all-reduce of the dots, of ||w||^2, halo exchange, all-reduce of alpha.  With
+// alpha fusion (default) the last one is folded into the next call's first all-reduce; the last call of a batch closes
+// its own alpha, so that every batch leaves a complete state behind (nalpha == nvec).
+int lanczos_call(eigenex_basis_s* b, bool last_in_batch) {
   hipStream_t st = b->ctx->stream;
+  const bool defer = fuses_alpha(b) && !last_in_batch;
   if (!b->started) {
     b->started = true;
     CHK(enq_initial_vector(b));
     bool merged = false;
-    CHK(enq_apply(b, 0, true, false, kFinishAlphaFirst, &merged));  // :389-392
-    if (!merged)
+    CHK(enq_apply(b, 0, true, false, kFinishAlphaFirst, &merged, defer));  // :389-392
+    if (defer)
+      b->alpha_pending = b->alpha_pending_first = true;
+    else if (!merged)
       for (auto& s : b->sh) launch_fin_alpha(st, s.ctrl, s.hbuf + b->slot_alpha(), s.alpha, 1, b->cap);  // :395
     b->h_nvec = 1;
     return 0;
@@ -983,13 +1060,19 @@ int lanczos_call(eigenex_basis_s* b) {
     count = kmod < nk - 1 ? (int)((nk - 1 - kmod + b->interval - 1) / b->interval) : 0;
     nq = kmod == 0 ? b->nq : 0;
   }
+  if (b->alpha_pending && count + nq == 0) CHK(close_pending_alpha(b));  // no dots pass to ride on
+  const bool fused = b->alpha_pending;
   bool merged = false;
-  CHK(enq_orthogonalize(b, EIGENEX_VEC_V, EIGENEX_VEC_W, true, k, first, stride, count, nq, false, false, kFinLanczos, &merged));
+  CHK(enq_orthogonalize(b, EIGENEX_VEC_V, EIGENEX_VEC_W, true, k, first, stride, count, nq, false, false, kFinLanczos, &merged, fused));
   if (!merged)
     for (auto& s : b->sh) launch_fin_norm(st, s.ctrl, s.hbuf + b->slot_nrm(), b->threshold, kFinLanczos, s.beta);  // :429-437
-  CHK(enq_apply(b, k + 1, true, false, kFinishAlpha, &merged));  // :439-445
-  if (!merged)
+  CHK(enq_apply(b, k + 1, true, false, kFinishAlpha, &merged, defer));  // :439-445
+  if (defer) {
+    b->alpha_pending = true;
+    b->alpha_pending_first = false;
+  } else if (!merged) {
     for (auto& s : b->sh) launch_fin_alpha(st, s.ctrl, s.hbuf + b->slot_alpha(), s.alpha, 0, b->cap);  // :448-450
+  }
   b->h_nvec++;
   return 0;
 }
@@ -1043,7 +1126,7 @@ void drop_step_graphs(eigenex_basis_s* b) {
 
 int enqueue_steps(eigenex_basis_s* b, int ncalls, int kind) {
   auto plain = [&]() -> int {
-    for (int i = 0; i < ncalls; ++i) CHK(kind == 0 ? lanczos_call(b) : arnoldi_call(b));
+    for (int i = 0; i < ncalls; ++i) CHK(kind == 0 ? lanczos_call(b, i == ncalls - 1) : arnoldi_call(b));
     return 0;
   };
   eigenex_context_s* c = b->ctx;
@@ -1310,6 +1393,20 @@ int eigenex_context_info(eigenex_context_t c, int* rank, int* world_size, int* n
   if (world_size) *world_size = c->world;
   if (nshards_total) *nshards_total = c->P;
   if (nshards_local) *nshards_local = (int)c->local.size();
+  return 0;
+}
+
+int eigenex_context_comm_info(eigenex_context_t c, int* comm_ranks, int* comm_rank, int* comm_device) {
+  if (!c) return fail(EIGENEX_ERR_ARG, "ctx is NULL");
+  int n = 0, r = 0, d = c->device;
+  if (c->comm) {
+    NCCLCHK(ncclCommCount(c->comm, &n));
+    NCCLCHK(ncclCommUserRank(c->comm, &r));
+    NCCLCHK(ncclCommCuDevice(c->comm, &d));
+  }
+  if (comm_ranks) *comm_ranks = n;
+  if (comm_rank) *comm_rank = r;
+  if (comm_device) *comm_device = d;
   return 0;
 }
 
@@ -1734,10 +1831,10 @@ int eigenex_basis_create_ex(eigenex_context_t c, eigenex_csr_t csr, int64_t n_gl
       // room for eigenex_basis_tune up to kMaxBlocksPerCu workgroups per CU
       s.pstride = std::max(grid_for_tiles((s.nd + kTileRows - 1) / kTileRows, kMaxBlocksPerCu),
                            grid_for_tiles((s.nloc + kSpmvRows - 1) / kSpmvRows, kMaxBlocksPerCu));
-      const int rows = 2 * std::max(b->maxcols, 8) + 4;
+      const int rows = 4 * std::max(b->maxcols, 8) + 4;  // two dot sets of a complex column set (fused-alpha step)
       HIPCHK(hipMalloc(&s.partials, sizeof(double) * (size_t)s.pstride * rows));
-      HIPCHK(hipMalloc(&s.hbuf, sizeof(double) * (4 * b->maxcols + 48)));
-      HIPCHK(hipMemsetAsync(s.hbuf, 0, sizeof(double) * (4 * b->maxcols + 48), c->stream));
+      HIPCHK(hipMalloc(&s.hbuf, sizeof(double) * b->hbuf_len()));
+      HIPCHK(hipMemsetAsync(s.hbuf, 0, sizeof(double) * b->hbuf_len(), c->stream));
       HIPCHK(hipMalloc(&s.alpha, sizeof(double) * (capacity + 2)));
       HIPCHK(hipMalloc(&s.beta, sizeof(double) * (capacity + 2)));
       HIPCHK(hipMemsetAsync(s.alpha, 0, sizeof(double) * (capacity + 2), c->stream));
@@ -1806,10 +1903,10 @@ int eigenex_basis_reserve(eigenex_basis_t b, int capacity) {
     HIPCHK(hipMalloc(&V, vbytes * capacity));
     HIPCHK(hipMemcpyAsync(V, s.V, vbytes * oldcap, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipMemsetAsync(V + (size_t)s.ldd * oldcap, 0, vbytes * (capacity - oldcap), c->stream));
-    const int rows = 2 * std::max(newmax, 8) + 4;
+    const int rows = 4 * std::max(newmax, 8) + 4;
     HIPCHK(hipMalloc(&partials, sizeof(double) * (size_t)s.pstride * rows));
-    HIPCHK(hipMalloc(&hbuf, sizeof(double) * (4 * newmax + 48)));
-    HIPCHK(hipMemsetAsync(hbuf, 0, sizeof(double) * (4 * newmax + 48), c->stream));
+    HIPCHK(hipMalloc(&hbuf, sizeof(double) * (8 * newmax + 64)));
+    HIPCHK(hipMemsetAsync(hbuf, 0, sizeof(double) * (8 * newmax + 64), c->stream));
     HIPCHK(hipMalloc(&alpha, sizeof(double) * (capacity + 2)));
     HIPCHK(hipMalloc(&beta, sizeof(double) * (capacity + 2)));
     HIPCHK(hipMemsetAsync(alpha, 0, sizeof(double) * (capacity + 2), c->stream));
@@ -1861,6 +1958,13 @@ int eigenex_basis_clear(eigenex_basis_t b) {
   for (auto& s : b->sh) HIPCHK(hipMemsetAsync(s.ctrl, 0, sizeof(Ctrl), b->ctx->stream));
   b->started = false;
   b->h_nvec = 0;
+  b->alpha_pending = false;
+  return 0;
+}
+
+int eigenex_basis_set_alpha_fusion(eigenex_basis_t b, int on) {
+  if (!b) return fail(EIGENEX_ERR_ARG, "basis is NULL");
+  b->fuse_alpha = on != 0;
   return 0;
 }
 

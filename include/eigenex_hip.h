@@ -120,6 +120,9 @@ int eigenex_context_destroy(eigenex_context_t ctx);
 int eigenex_context_selftest(eigenex_context_t ctx, int* ok);
 int eigenex_context_sync(eigenex_context_t ctx);
 int eigenex_context_info(eigenex_context_t ctx, int* rank, int* world_size, int* nshards_total, int* nshards_local);
+/* what the RCCL communicator itself reports (ncclCommCount / ncclCommUserRank / ncclCommCuDevice): *comm_ranks = 0
+ * when the context has no communicator (single GPU, loopback) */
+int eigenex_context_comm_info(eigenex_context_t ctx, int* comm_ranks, int* comm_rank, int* comm_device);
 /* the context's hipStream_t (as void*) */
 void* eigenex_context_stream(eigenex_context_t ctx);
 
@@ -217,6 +220,11 @@ int eigenex_basis_capacity(eigenex_basis_t b, int* capacity);
 int eigenex_basis_tune(eigenex_basis_t b, int vec_blocks_per_cu, int spmv_blocks_per_cu, int flags);
 /* clearLanczosSteps()/clearArnoldiSteps(): forget vectors and coefficients, keep settings */
 int eigenex_basis_clear(eigenex_basis_t b);
+/* Lanczos between shards (more than one shard, batched schemes): by default alpha_{k+1} = u_{k+1}.v (lanczos.hpp:448) is not
+ * all-reduced on its own after the operator but travels with the next step's dots (together with the Gram column
+ * V^H u_{k+1}, from which h = V^H w0 is formed exactly): 2 instead of 3 all-reduces per step, results equal to rounding.
+ * on = 0 restores one all-reduce per scalar.  Single-shard contexts are not affected. */
+int eigenex_basis_set_alpha_fusion(eigenex_basis_t b, int on);
 
 /* host <-> device vectors (rows owned by this context) */
 int eigenex_vec_upload(eigenex_basis_t b, int vec_ref, const double* host);

@@ -550,3 +550,82 @@ def test_large_batches_and_sequential_scheme_are_not_recorded_as_graphs(mods):
         np.testing.assert_allclose(th[:5], alphas[1][:5], rtol=0, atol=1e-10)
         np.testing.assert_allclose(th[-5:], alphas[1][-5:], rtol=0, atol=1e-10)
     ctx.close()
+
+
+@pytest.mark.parametrize("shards", [2, 3, 5])
+def test_alpha_rides_on_the_dots_allreduce_between_shards(mods, shards):
+    """between shards the Lanczos step needs 2 all-reduces instead of 3 -- alpha_{k+1} = u_{k+1}.v
+    (lanczos.hpp:448) travels with the next step's dots, together with the Gram column V^H u_{k+1} from which
+    h = V^H (v - alpha u - beta u_prev) is formed exactly (enq_fused_dots).  Checked on the loopback transport (the
+    same enqueue code as RCCL): coefficients against the C oracle for full, strided and deflated re-orthogonalisation,
+    with and without a shift; fused and unfused runs agree to rounding; batches of any size leave a complete state
+    (nalpha == nvec) behind; the library's own count of collectives per step drops from 4 (3 all-reduces + halo) to 3."""
+    capi, _ = mods
+    n = 12
+    N = n ** 3
+    rowptr, col, val = cref.laplacian3d(n)
+    rng = np.random.default_rng(15)
+    init = rng.standard_normal(N)
+    Q = np.linalg.qr(rng.standard_normal((N, 3)))[0].T.copy()
+    m = 30
+    ctx = capi.Context(loopback_shards=shards)
+    A = capi.Csr.upload(ctx, N, rowptr, col, val)
+    for interval, nq, shift in ((1, 0, 0.0), (1, 3, 0.4), (3, 2, -0.7)):
+        ref = cref.CLanczos(rowptr, col, val, init, cap=m + 2, shift=shift, interval=interval, Q=list(Q[:nq]))
+        assert ref.run(m + 1) == m + 1
+        got = {}
+        for fused in (True, False):
+            b = capi.Basis(ctx, A, N, m + 1, nq)
+            b.configure(shift, 1e-12, interval, capi.ORTHO_BATCHED)
+            b.set_alpha_fusion(fused)
+            for q in range(nq):
+                b.upload(capi.VEC_ORTHO(q), Q[q])
+            b.upload(capi.VEC_W, init)
+            ctx.profile_reset()
+            ctx.profile_enable(True)
+            for batch in (1, 3, 1, m + 1 - 5):  # every batch closes its own alpha
+                b.lanczos_enqueue(batch)
+                st, alpha, beta = b.lanczos_state()
+                assert st.nalpha == st.nvec and st.nbeta == st.nvec - 1 and st.stopped == 0
+            ctx.profile_enable(False)
+            comm = ctx.profile_get(capi.K_COMM)[0]
+            assert (st.nvec, st.iterations, st.calls_true) == (m + 1, m, m + 1)
+            tol = 1e-12 if interval == 1 else 1e-9
+            np.testing.assert_allclose(alpha, ref.alpha, rtol=0, atol=tol)
+            np.testing.assert_allclose(beta, ref.beta, rtol=0, atol=tol)
+            got[fused] = (alpha, beta, comm)
+            if interval == 1:
+                V = np.stack([b.download(capi.VEC_COL(c)) for c in range(m + 1)])
+                assert np.abs(V @ V.T - np.eye(m + 1)).max() < 1e-13
+            b.close()
+        np.testing.assert_allclose(got[True][0], got[False][0], rtol=0, atol=1e-12 if interval == 1 else 1e-9)
+        if interval == 1:
+            # unfused: per step dots, norm, halo, alpha = 4 booked collectives; fused: 3, plus one alpha per batch
+            assert got[False][2] - got[True][2] >= m - 4 - 1, got
+    # complex Hermitian operator (tridiagonal +-i hopping, the reference's sample_lanczos2.cpp:19-28 shape)
+    Nc = 600
+    d = np.zeros(Nc)
+    rp = np.zeros(Nc + 1, np.int32)
+    cc, vv = [], []
+    for i in range(Nc):
+        if i > 0:
+            cc.append(i - 1), vv.append(1j)
+        cc.append(i), vv.append(0.1 * np.cos(i))
+        if i < Nc - 1:
+            cc.append(i + 1), vv.append(-1j)
+        rp[i + 1] = len(cc)
+    Az = capi.Csr.upload(ctx, Nc, rp, np.array(cc, np.int32), np.array(vv, np.complex128))
+    zinit = rng.standard_normal(Nc) + 1j * rng.standard_normal(Nc)
+    res = {}
+    for fused in (True, False):
+        b = capi.Basis(ctx, Az, Nc, 41)
+        b.set_alpha_fusion(fused)
+        b.upload(capi.VEC_W, zinit)
+        b.lanczos_enqueue(41)
+        st, alpha, beta = b.lanczos_state()
+        assert (st.nvec, st.nalpha, st.stopped) == (41, 41, 0)
+        res[fused] = (alpha, beta)
+        b.close()
+    np.testing.assert_allclose(res[True][0], res[False][0], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(res[True][1], res[False][1], rtol=0, atol=1e-12)
+    ctx.close()
