@@ -65,6 +65,19 @@ SIGNATURES = {
     "eigenex_context_sync": (C.c_int, [_vp]),
     "eigenex_context_info": (C.c_int, [_vp] + [C.POINTER(C.c_int)] * 4),
     "eigenex_context_comm_info": (C.c_int, [_vp] + [C.POINTER(C.c_int)] * 3),
+    "eigenex_context_trace": (C.c_int, [_vp, C.c_int]),
+    "eigenex_context_trace_get": (C.c_int, [_vp, _ip, _ip, C.c_int, C.POINTER(C.c_int)]),
+    "eigenex_plan_create": (C.c_int, [C.c_int64, C.c_int, C.c_int, _ip, _ip, C.POINTER(_vp)]),
+    "eigenex_plan_destroy": (C.c_int, [_vp]),
+    "eigenex_plan_sizes": (C.c_int, [_vp] + [C.POINTER(C.c_int64)] * 4 + [C.POINTER(C.c_int)] * 2 + [C.POINTER(C.c_int64)]),
+    "eigenex_plan_local_columns": (C.c_int, [_vp, _ip]),
+    "eigenex_plan_halo_columns": (C.c_int, [_vp, _ip]),
+    "eigenex_plan_recv_segments": (C.c_int, [_vp, _ip, _lp, _lp]),
+    "eigenex_plan_add_request": (C.c_int, [_vp, C.c_int, _ip, C.c_int64]),
+    "eigenex_plan_send_segments": (C.c_int, [_vp, _ip, _lp, _lp, _lp]),
+    "eigenex_plan_send_rows": (C.c_int, [_vp, _ip]),
+    "eigenex_lanczos_collectives": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              _ip, _ip, C.c_int, C.POINTER(C.c_int)]),
     "eigenex_context_stream": (_vp, [_vp]),
     "eigenex_profile_enable": (C.c_int, [_vp, C.c_int]),
     "eigenex_profile_reset": (C.c_int, [_vp]),
@@ -102,6 +115,7 @@ SIGNATURES = {
     "eigenex_scale": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double]),
     "eigenex_lanczos_enqueue": (C.c_int, [_vp, C.c_int]),
     "eigenex_basis_set_alpha_fusion": (C.c_int, [_vp, C.c_int]),
+    "eigenex_basis_clone": (C.c_int, [_vp, C.POINTER(_vp)]),
     "eigenex_arnoldi_enqueue": (C.c_int, [_vp, C.c_int]),
     "eigenex_lanczos_restart": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double]),
     "eigenex_lanczos_state": (C.c_int, [_vp, C.POINTER(State), _dp, _dp]),
@@ -129,6 +143,35 @@ def _preload_torch_runtime():
             pass
 
 
+def _hip_runtimes_mapped():
+    """distinct libamdhip64 / librccl files mapped into this process (from /proc/self/maps)"""
+    found = {"libamdhip64": set(), "librccl": set()}
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.rsplit(None, 1)[-1]
+                base = os.path.basename(path)
+                for k in found:
+                    if base.startswith(k + ".so"):
+                        found[k].add(os.path.realpath(path))
+    except OSError:
+        pass
+    return found
+
+
+def _refuse_mixed_runtimes():
+    """Two copies of the HIP (or RCCL) runtime in one process -- the system one this library links against and the
+    one a PyTorch-ROCm wheel bundles under the same SONAME -- end in an abort at interpreter exit ("double free or
+    corruption") long after the cause.  That can only happen when something loaded one copy by path before the other
+    was resolved by name; refuse right here, where the order can still be fixed."""
+    for name, paths in _hip_runtimes_mapped().items():
+        if len(paths) > 1:
+            raise EigenexError(
+                f"two copies of {name} are loaded in this process ({', '.join(sorted(paths))}): import torch BEFORE anything "
+                "loads the system ROCm runtime (cmpt_eigenex_amd.capi does so by itself unless EIGENEX_NO_TORCH_PRELOAD is set), "
+                "or do not import torch in this process at all")
+
+
 def lib():
     """Load libeigenex_hip.so (built in-tree by cmpt_eigenex_amd.build).  Fails loudly if missing."""
     global _LIB
@@ -139,6 +182,7 @@ def lib():
                 "(there is no CPU fallback for the Krylov hot path)")
         _preload_torch_runtime()
         L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        _refuse_mixed_runtimes()
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype = res
@@ -183,6 +227,83 @@ def halo_plan(n_global: int, nshards: int, shard: int, col_global: np.ndarray):
     return cols, per
 
 
+COLL_ALLREDUCE, COLL_HALO = 1, 2
+
+
+def lanczos_collectives(call_index: int, last_in_batch: bool, alpha_pending: bool, interval=1, n_ortho=0, ortho_mode=ORTHO_BATCHED,
+                        alpha_fusion=True, is_complex=False):
+    """[(op, count), ...] of one Lanczos step call between shards, and the alpha-fusion state after it"""
+    pend = C.c_int(int(alpha_pending))
+    n = C.c_int()
+    ops, cnt = np.zeros(4096, np.int32), np.zeros(4096, np.int32)
+    _chk(lib().eigenex_lanczos_collectives(call_index, int(last_in_batch), C.byref(pend), interval, n_ortho, ortho_mode, int(alpha_fusion),
+                                           int(is_complex), _i(ops), _i(cnt), ops.size, C.byref(n)))
+    return [(int(ops[i]), int(cnt[i])) for i in range(n.value)], bool(pend.value)
+
+
+class ShardPlan:
+    """eigenex_plan_*: the host-side plan of one CSR row shard (no GPU).  rowptr relative to the shard's first row,
+    col with GLOBAL column indices."""
+
+    def __init__(self, n_global: int, nshards: int, shard: int, rowptr, col_global):
+        self.h = _vp()
+        rp = np.ascontiguousarray(rowptr, np.int32)
+        cl = np.ascontiguousarray(col_global, np.int32)
+        _chk(lib().eigenex_plan_create(n_global, nshards, shard, _i(rp), _i(cl), C.byref(self.h)))
+
+    def sizes(self):
+        a = [C.c_int64() for _ in range(4)]
+        b = [C.c_int() for _ in range(2)]
+        c = C.c_int64()
+        _chk(lib().eigenex_plan_sizes(self.h, *[C.byref(x) for x in a], *[C.byref(x) for x in b], C.byref(c)))
+        return dict(n_local=a[0].value, n_pad=a[1].value, nnz=a[2].value, n_halo=a[3].value, n_recv=b[0].value, n_send=b[1].value,
+                    n_send_rows=c.value)
+
+    def local_columns(self):
+        out = np.zeros(max(self.sizes()["nnz"], 1), np.int32)
+        _chk(lib().eigenex_plan_local_columns(self.h, _i(out)))
+        return out[: self.sizes()["nnz"]]
+
+    def halo_columns(self):
+        out = np.zeros(max(self.sizes()["n_halo"], 1), np.int32)
+        _chk(lib().eigenex_plan_halo_columns(self.h, _i(out)))
+        return out[: self.sizes()["n_halo"]]
+
+    def recv_segments(self):
+        n = self.sizes()["n_recv"]
+        peer, off, cnt = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int64), np.zeros(max(n, 1), np.int64)
+        _chk(lib().eigenex_plan_recv_segments(self.h, _i(peer), off.ctypes.data_as(_lp), cnt.ctypes.data_as(_lp)))
+        return [(int(peer[i]), int(off[i]), int(cnt[i])) for i in range(n)]
+
+    def add_request(self, from_shard: int, rows_global):
+        r = np.ascontiguousarray(rows_global, np.int32)
+        _chk(lib().eigenex_plan_add_request(self.h, from_shard, _i(r), r.size))
+
+    def send_segments(self):
+        n = self.sizes()["n_send"]
+        peer = np.zeros(max(n, 1), np.int32)
+        off, cnt, cs = (np.zeros(max(n, 1), np.int64) for _ in range(3))
+        _chk(lib().eigenex_plan_send_segments(self.h, _i(peer), *[x.ctypes.data_as(_lp) for x in (off, cnt, cs)]))
+        return [(int(peer[i]), int(off[i]), int(cnt[i]), int(cs[i])) for i in range(n)]
+
+    def send_rows(self):
+        n = self.sizes()["n_send_rows"]
+        out = np.zeros(max(n, 1), np.int32)
+        _chk(lib().eigenex_plan_send_rows(self.h, _i(out)))
+        return out[:n]
+
+    def close(self):
+        if self.h:
+            lib().eigenex_plan_destroy(self.h)
+            self.h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def rccl_unique_id() -> bytes:
     buf = C.create_string_buffer(128)
     _chk(lib().eigenex_rccl_unique_id(buf))
@@ -202,6 +323,16 @@ class Context:
         v = [C.c_int() for _ in range(4)]
         _chk(lib().eigenex_context_info(self.h, *[C.byref(x) for x in v]))
         return dict(zip(("rank", "world_size", "nshards_total", "nshards_local"), (x.value for x in v)))
+
+    def trace(self, on=True):
+        _chk(lib().eigenex_context_trace(self.h, int(on)))
+
+    def trace_get(self):
+        n = C.c_int()
+        _chk(lib().eigenex_context_trace_get(self.h, None, None, 0, C.byref(n)))
+        ops, cnt = np.zeros(max(n.value, 1), np.int32), np.zeros(max(n.value, 1), np.int32)
+        _chk(lib().eigenex_context_trace_get(self.h, _i(ops), _i(cnt), ops.size, C.byref(n)))
+        return [(int(ops[i]), int(cnt[i])) for i in range(n.value)]
 
     def comm_info(self):
         """(ranks, rank, device) as the RCCL communicator reports them; ranks = 0 without a communicator"""

@@ -111,6 +111,8 @@ struct eigenex_context_s {
   hipStream_t stream = nullptr;
   ncclComm_t comm = nullptr;
   bool profiling = false;
+  bool tracing = false;                      // record every collective the step drivers enqueue (tests)
+  std::vector<std::pair<int, int>> trace;    // (EIGENEX_COLL_*, doubles per shard)
   std::vector<ProfRec> recs;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
   size_t pool_used = 0;
@@ -290,6 +292,7 @@ namespace {
 int allreduce(eigenex_basis_s* b, int off, int n) {
   eigenex_context_s* c = b->ctx;
   if ((c->P == 1 && !c->comm) || n <= 0) return 0;  // a 1-rank communicator (self-test) still goes through RCCL
+  if (c->tracing) c->trace.push_back({EIGENEX_COLL_ALLREDUCE, n});
   ProfScope ps(c, EIGENEX_K_COMM, 0.0);
   if (c->loopback) {
     PtrPack pk;
@@ -306,6 +309,7 @@ int allreduce(eigenex_basis_s* b, int off, int n) {
 int halo_exchange(eigenex_basis_s* b, bool use_ctrl = true) {
   eigenex_context_s* c = b->ctx;
   if (c->P == 1 || !b->csr) return 0;
+  if (c->tracing) c->trace.push_back({EIGENEX_COLL_HALO, 0});
   ProfScope ps(c, EIGENEX_K_COMM, 0.0);
   // pack non-contiguous send segments
   for (auto& bs : b->sh) {
@@ -455,11 +459,13 @@ int choose_column_blocks(const CsrShard& s, const std::vector<int32_t>& lcol, co
   return K;
 }
 
-int build_shard_host(eigenex_context_s* c, int64_t n_global, int gshard, const int32_t* rowptr, const int32_t* col,
-                     const double* val, int es, int column_blocks, CsrShard& s) {
+// The host-only half of a row shard: ranges, halo slots, local column numbering, receive segments.  No device call:
+// eigenex_plan_create exposes exactly this to hosts without a GPU (the gloo tests drive it across real processes).
+int plan_shard_host(int64_t n_global, int P, int gshard, const int32_t* rowptr, const int32_t* col, int es, CsrShard& s,
+                    std::vector<int32_t>& lcol) {
   s.gshard = gshard;
   s.es = es;
-  partition(n_global, c->P, gshard, &s.rb, &s.re);
+  partition(n_global, P, gshard, &s.rb, &s.re);
   s.nloc = s.re - s.rb;
   s.npad = pad_rows(s.nloc);
   const int64_t p0 = rowptr[0];
@@ -476,7 +482,7 @@ int build_shard_host(eigenex_context_s* c, int64_t n_global, int gshard, const i
   s.halo_cols.swap(rem);
   s.nhalo = (int64_t)s.halo_cols.size();
   if (s.npad + s.nhalo > 2147483647) return fail(EIGENEX_ERR_ARG, "local + halo columns exceed int32");
-  std::vector<int32_t> lcol((size_t)s.nnz + 8, 0);
+  lcol.assign((size_t)s.nnz + 8, 0);
   for (int64_t p = 0; p < s.nnz; ++p) {
     const int64_t cg = col[p0 + p];
     if (cg >= s.rb && cg < s.re)
@@ -485,6 +491,15 @@ int build_shard_host(eigenex_context_s* c, int64_t n_global, int gshard, const i
       lcol[p] = (int32_t)(s.npad + (std::lower_bound(s.halo_cols.begin(), s.halo_cols.end(), (int32_t)cg) -
                                     s.halo_cols.begin()));
   }
+  build_recv(s, n_global, P);
+  return 0;
+}
+
+int build_shard_host(eigenex_context_s* c, int64_t n_global, int gshard, const int32_t* rowptr, const int32_t* col,
+                     const double* val, int es, int column_blocks, CsrShard& s) {
+  std::vector<int32_t> lcol;
+  CHK(plan_shard_host(n_global, c->P, gshard, rowptr, col, es, s, lcol));
+  const int64_t p0 = rowptr[0];
   std::vector<int32_t> lrp((size_t)s.nloc + 1);
   for (int64_t i = 0; i <= s.nloc; ++i) lrp[i] = (int32_t)(rowptr[i] - p0);
   const double* vsrc = val + p0 * es;
@@ -530,7 +545,6 @@ int build_shard_host(eigenex_context_s* c, int64_t n_global, int gshard, const i
   HIPCHK(hipMemcpyAsync(s.col, lcol.data(), sizeof(int32_t) * (s.nnz + 8), hipMemcpyHostToDevice, c->stream));
   if (s.nnz) HIPCHK(hipMemcpyAsync(s.val, vsrc, sizeof(double) * s.nnz * es, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  build_recv(s, n_global, c->P);
   return 0;
 }
 
@@ -1014,6 +1028,18 @@ int enq_initial_vector(eigenex_basis_s* b) {
   return 0;
 }
 
+// columns a Lanczos step with k+1 existing vectors re-orthogonalises against  (lanczos.hpp:411-426)
+inline void lanczos_columns(int k, int64_t interval, int nq_total, int* first, int* stride, int* count, int* nq) {
+  *first = 0, *stride = 1, *count = 0, *nq = 0;
+  if (interval <= 0) return;
+  const int64_t nk = k + 2;  // lanczosvectors_.size() after the push_back
+  const int64_t kmod = (nk - 1) % interval;
+  *first = (int)kmod;
+  *stride = (int)std::min<int64_t>(interval, 1 << 30);
+  *count = kmod < nk - 1 ? (int)((nk - 1 - kmod + interval - 1) / interval) : 0;
+  *nq = kmod == 0 ? nq_total : 0;
+}
+
 // Can the alpha of the vector a call adds stay un-reduced until the next call's dots?  Only between shards (one shard
 // merges its tiny launches instead), with a device operator and a batched scheme.
 inline bool fuses_alpha(const eigenex_basis_s* b) {
@@ -1050,16 +1076,8 @@ int lanczos_call(eigenex_basis_s* b, bool last_in_batch) {
   }
   const int k = b->h_nvec - 1;
   if (b->h_nvec >= b->cap) return fail(EIGENEX_ERR_STATE, "basis capacity exhausted");
-  // columns to re-orthogonalise against  (:411-426)
-  int first = 0, stride = 1, count = 0, nq = 0;
-  if (b->interval > 0) {
-    const int64_t nk = k + 2;  // lanczosvectors_.size() after the push_back
-    const int64_t kmod = (nk - 1) % b->interval;
-    first = (int)kmod;
-    stride = (int)std::min<int64_t>(b->interval, 1 << 30);
-    count = kmod < nk - 1 ? (int)((nk - 1 - kmod + b->interval - 1) / b->interval) : 0;
-    nq = kmod == 0 ? b->nq : 0;
-  }
+  int first, stride, count, nq;
+  lanczos_columns(k, b->interval, b->nq, &first, &stride, &count, &nq);
   if (b->alpha_pending && count + nq == 0) CHK(close_pending_alpha(b));  // no dots pass to ride on
   const bool fused = b->alpha_pending;
   bool merged = false;
@@ -1254,6 +1272,171 @@ int eigenex_halo_plan(int64_t n_global, int nshards, int shard, int64_t nnz, con
   if (count_per_owner) {
     for (int o = 0; o < nshards; ++o) count_per_owner[o] = 0;
     for (int32_t c : rem) count_per_owner[owner_of(n_global, nshards, c)]++;
+  }
+  return 0;
+}
+
+// ---- shard plan on the host (no GPU): what eigenex_csr_upload computes before it copies anything -----------------
+}  // extern "C"
+struct eigenex_plan_s {
+  int64_t n_global = 0;
+  int P = 1;
+  CsrShard s;
+  std::vector<int32_t> lcol, send_rows;
+};
+extern "C" {
+
+int eigenex_plan_create(int64_t n_global, int nshards, int shard, const int32_t* rowptr, const int32_t* col_global, eigenex_plan_t* out) {
+  if (!out || !rowptr || n_global <= 0 || nshards <= 0 || shard < 0 || shard >= nshards) return fail(EIGENEX_ERR_ARG, "eigenex_plan_create: bad argument");
+  int64_t rb, re;
+  partition(n_global, nshards, shard, &rb, &re);
+  if (rowptr[0] < 0) return fail(EIGENEX_ERR_ARG, "row pointers must be non-negative");
+  for (int64_t i = 0; i < re - rb; ++i)
+    if (rowptr[i + 1] < rowptr[i]) return fail(EIGENEX_ERR_ARG, "row pointers are not non-decreasing");
+  if (re > rb && rowptr[re - rb] > rowptr[0] && !col_global) return fail(EIGENEX_ERR_ARG, "col is NULL");
+  auto* p = new eigenex_plan_s();
+  p->n_global = n_global;
+  p->P = nshards;
+  const int rc = plan_shard_host(n_global, nshards, shard, rowptr, col_global, 1, p->s, p->lcol);
+  if (rc) {
+    delete p;
+    return rc;
+  }
+  *out = p;
+  return 0;
+}
+
+int eigenex_plan_destroy(eigenex_plan_t p) {
+  delete p;
+  return 0;
+}
+
+int eigenex_plan_sizes(eigenex_plan_t p, int64_t* n_local, int64_t* n_pad, int64_t* nnz, int64_t* n_halo, int* n_recv, int* n_send,
+                       int64_t* n_send_rows) {
+  if (!p) return fail(EIGENEX_ERR_ARG, "plan is NULL");
+  if (n_local) *n_local = p->s.nloc;
+  if (n_pad) *n_pad = p->s.npad;
+  if (nnz) *nnz = p->s.nnz;
+  if (n_halo) *n_halo = p->s.nhalo;
+  if (n_recv) *n_recv = (int)p->s.recv.size();
+  if (n_send) *n_send = (int)p->s.send.size();
+  if (n_send_rows) *n_send_rows = (int64_t)p->send_rows.size();
+  return 0;
+}
+
+int eigenex_plan_local_columns(eigenex_plan_t p, int32_t* lcol) {
+  if (!p || !lcol) return fail(EIGENEX_ERR_ARG, "NULL argument");
+  std::copy(p->lcol.begin(), p->lcol.begin() + p->s.nnz, lcol);
+  return 0;
+}
+
+int eigenex_plan_halo_columns(eigenex_plan_t p, int32_t* cols_global) {
+  if (!p || !cols_global) return fail(EIGENEX_ERR_ARG, "NULL argument");
+  std::copy(p->s.halo_cols.begin(), p->s.halo_cols.end(), cols_global);
+  return 0;
+}
+
+int eigenex_plan_recv_segments(eigenex_plan_t p, int32_t* peer, int64_t* offset, int64_t* count) {
+  if (!p || !peer || !offset || !count) return fail(EIGENEX_ERR_ARG, "NULL argument");
+  for (size_t i = 0; i < p->s.recv.size(); ++i) peer[i] = p->s.recv[i].peer, offset[i] = p->s.recv[i].offset, count[i] = p->s.recv[i].count;
+  return 0;
+}
+
+int eigenex_plan_add_request(eigenex_plan_t p, int from_shard, const int32_t* rows_global, int64_t count) {
+  if (!p || from_shard < 0 || from_shard >= p->P || from_shard == p->s.gshard || count < 0 || (count && !rows_global))
+    return fail(EIGENEX_ERR_ARG, "eigenex_plan_add_request: bad argument");
+  return add_send(p->s, from_shard, rows_global, count, p->send_rows);
+}
+
+int eigenex_plan_send_segments(eigenex_plan_t p, int32_t* peer, int64_t* offset, int64_t* count, int64_t* contig_start) {
+  if (!p || !peer || !offset || !count || !contig_start) return fail(EIGENEX_ERR_ARG, "NULL argument");
+  for (size_t i = 0; i < p->s.send.size(); ++i) {
+    peer[i] = p->s.send[i].peer, offset[i] = p->s.send[i].offset, count[i] = p->s.send[i].count;
+    contig_start[i] = p->s.send[i].contig_start;
+  }
+  return 0;
+}
+
+int eigenex_plan_send_rows(eigenex_plan_t p, int32_t* local_rows) {
+  if (!p || !local_rows) return fail(EIGENEX_ERR_ARG, "NULL argument");
+  std::copy(p->send_rows.begin(), p->send_rows.end(), local_rows);
+  return 0;
+}
+
+// The collectives ONE call of the Lanczos step driver enqueues between shards, in order: a description of
+// lanczos_call / enq_orthogonalize / enq_apply (a GPU test holds it against the trace of the real driver), so that a host
+// without a GPU can follow the same schedule (tests/test_multirank_gloo.py).
+int eigenex_lanczos_collectives(int call_index, int last_in_batch, int* alpha_pending, int64_t interval, int n_ortho, int ortho_mode,
+                                int alpha_fusion, int is_complex, int* ops, int* counts, int cap, int* n) {
+  if (call_index < 0 || !alpha_pending || !n || n_ortho < 0 || ortho_mode < EIGENEX_ORTHO_BATCHED || ortho_mode > EIGENEX_ORTHO_BATCHED_ADAPTIVE)
+    return fail(EIGENEX_ERR_ARG, "eigenex_lanczos_collectives: bad argument");
+  const int es = is_complex ? 2 : 1;
+  std::vector<std::pair<int, int>> out;
+  auto allred = [&](int cnt) {
+    if (cnt > 0) out.push_back({EIGENEX_COLL_ALLREDUCE, cnt});
+  };
+  // Gram-Schmidt of one vector against ncols columns (enq_orthogonalize); `fused`: the dots all-reduce carries alpha
+  auto ortho = [&](int ncols, bool three_term, bool fused) {
+    int mode = ortho_mode;
+    if (mode == EIGENEX_ORTHO_BATCHED_ADAPTIVE) mode = (three_term || ncols == 0) ? EIGENEX_ORTHO_BATCHED : EIGENEX_ORTHO_BATCHED_TWICE;
+    if (mode == EIGENEX_ORTHO_SEQUENTIAL) {
+      if (ncols == 0) allred(1);
+      for (int i = 0; i < ncols; ++i) {
+        allred(es);
+        if (i == ncols - 1) allred(1);
+      }
+      return;
+    }
+    const bool twice = mode == EIGENEX_ORTHO_BATCHED_TWICE && ncols > 0;
+    allred(fused ? 2 + 2 * ncols * es : ncols * es);
+    if (!twice) {
+      allred(1);
+      return;
+    }
+    allred(ncols * es);
+    allred(1);
+  };
+  const bool can_fuse = alpha_fusion && ortho_mode != EIGENEX_ORTHO_SEQUENTIAL;
+  const bool defer = can_fuse && !last_in_batch;
+  if (call_index == 0) {
+    ortho(n_ortho, false, false);  // start vector against orthogonalizingVectors_, norm
+  } else {
+    int first, stride, count, nq;
+    lanczos_columns(call_index - 1, interval, n_ortho, &first, &stride, &count, &nq);
+    if (*alpha_pending && count + nq == 0) {
+      allred(es);
+      *alpha_pending = 0;
+    }
+    ortho(count + nq, true, *alpha_pending != 0);
+  }
+  out.push_back({EIGENEX_COLL_HALO, 0});
+  if (defer)
+    *alpha_pending = 1;
+  else {
+    allred(es);
+    *alpha_pending = 0;
+  }
+  *n = (int)out.size();
+  if (ops && counts) {
+    if (cap < *n) return fail(EIGENEX_ERR_ARG, "eigenex_lanczos_collectives: cap too small");
+    for (int i = 0; i < *n; ++i) ops[i] = out[i].first, counts[i] = out[i].second;
+  }
+  return 0;
+}
+
+int eigenex_context_trace(eigenex_context_t c, int on) {
+  if (!c) return fail(EIGENEX_ERR_ARG, "ctx is NULL");
+  c->tracing = on != 0;
+  if (on) c->trace.clear();
+  return 0;
+}
+
+int eigenex_context_trace_get(eigenex_context_t c, int* ops, int* counts, int cap, int* n) {
+  if (!c || !n) return fail(EIGENEX_ERR_ARG, "NULL argument");
+  *n = (int)c->trace.size();
+  if (ops && counts) {
+    if (cap < *n) return fail(EIGENEX_ERR_ARG, "cap too small");
+    for (int i = 0; i < *n; ++i) ops[i] = c->trace[i].first, counts[i] = c->trace[i].second;
   }
   return 0;
 }
@@ -1861,6 +2044,50 @@ int eigenex_basis_create_ex(eigenex_context_t c, eigenex_csr_t csr, int64_t n_gl
     return 0;
   };
   int rc = body();
+  if (rc) {
+    std::string keep = g_err;
+    eigenex_basis_destroy(b);
+    g_err = keep;
+    return rc;
+  }
+  *out = b;
+  return 0;
+}
+
+// Deep copy of a Krylov state (same context and operator): what copying a solver object means in the reference, whose
+// classes are implicitly copyable and own their vectors (lanczos.hpp:104-105, :233-239).  Device-to-device.
+int eigenex_basis_clone(eigenex_basis_t src, eigenex_basis_t* out) {
+  if (!src || !out) return fail(EIGENEX_ERR_ARG, "eigenex_basis_clone: NULL argument");
+  eigenex_context_s* c = src->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  eigenex_basis_t b = nullptr;
+  CHK(eigenex_basis_create_ex(c, src->csr, src->n_global, src->cap, src->nq, src->es == 2, &b));
+  b->shift = src->shift, b->shift_im = src->shift_im, b->threshold = src->threshold, b->interval = src->interval;
+  b->ortho_mode = src->ortho_mode, b->started = src->started, b->h_nvec = src->h_nvec, b->fn = src->fn, b->fn_user = src->fn_user;
+  b->fuse_alpha = src->fuse_alpha, b->alpha_pending = src->alpha_pending, b->alpha_pending_first = src->alpha_pending_first;
+  auto body = [&]() -> int {
+    for (size_t i = 0; i < b->sh.size(); ++i) {
+      BasisShard &d = b->sh[i], &s = src->sh[i];
+      d.g_vec = s.g_vec, d.g_spmv = s.g_spmv, d.spmv_flags = s.spmv_flags;
+      const size_t vb = sizeof(double) * (size_t)s.ldd;
+      auto cp = [&](void* to, const void* from, size_t bytes) { return hipMemcpyAsync(to, from, bytes, hipMemcpyDeviceToDevice, c->stream); };
+      HIPCHK(cp(d.V, s.V, vb * src->cap));
+      if (src->nq) HIPCHK(cp(d.Q, s.Q, vb * src->nq));
+      HIPCHK(cp(d.v, s.v, vb));
+      HIPCHK(cp(d.start, s.start, vb));
+      HIPCHK(cp(d.w, s.w, sizeof(double) * (size_t)(s.ldv + s.nhalo + 8) * s.es));
+      HIPCHK(cp(d.hbuf, s.hbuf, sizeof(double) * src->hbuf_len()));
+      HIPCHK(cp(d.alpha, s.alpha, sizeof(double) * (src->cap + 2)));
+      HIPCHK(cp(d.beta, s.beta, sizeof(double) * (src->cap + 2)));
+      HIPCHK(cp(d.H, s.H, sizeof(double) * (size_t)src->ldh * (src->cap + 1) * s.es));
+      HIPCHK(cp(d.ctrl, s.ctrl, sizeof(Ctrl)));
+      HIPCHK(cp(d.ctrl_pass2, s.ctrl_pass2, sizeof(Ctrl)));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+  };
+  const int rc = body();
   if (rc) {
     std::string keep = g_err;
     eigenex_basis_destroy(b);

@@ -142,8 +142,11 @@ class ArnoldiBase {
   RealScalar residue() const { return residue_; }
 
   ArnoldiBase() { setAllSettingsDefault(); }
-  ArnoldiBase(const ArnoldiBase&) = delete;
-  ArnoldiBase& operator=(const ArnoldiBase&) = delete;
+  // copyable and movable like the reference's class (implicit copy, arnoldi.hpp:53): deep copy of the device state
+  ArnoldiBase(const ArnoldiBase&) = default;
+  ArnoldiBase& operator=(const ArnoldiBase&) = default;
+  ArnoldiBase(ArnoldiBase&&) = default;
+  ArnoldiBase& operator=(ArnoldiBase&&) = default;
 
   // (reference :208-218)
   ArnoldiBase& setAllSettingsDefault() {
@@ -554,6 +557,24 @@ class ArnoldiEigenSolver {
     return convergenceLog_;
   }
   ComputationInfo info() const { return info_; }
+  // des() (reference :670 returns its Eigen::EigenSolver / ComplexEigenSolver of the Hessenberg matrix): a view of
+  // the eigen-decomposition of the CURRENT Hessenberg matrix, computed on demand -- eigenvalues() in the order the
+  // solver itself uses (descending modulus, :813-819) and eigenvectors() column k for eigenvalue k
+  class DenseSolverView {
+   public:
+    explicit DenseSolverView(const ArnoldiEigenSolver* s) : s_(s) {}
+    ComplexVectorType eigenvalues() const { return s_->hessenbergEigen_(nullptr); }
+    ComplexMatrixType eigenvectors() const {
+      ComplexMatrixType m;
+      s_->hessenbergEigen_(&m);
+      return m;
+    }
+    ComputationInfo info() const { return ComputationInfo::Success; }
+
+   private:
+    const ArnoldiEigenSolver* s_;
+  };
+  DenseSolverView des() const { return DenseSolverView(this); }
 
   ArnoldiEigenSolver() { setAllSettingsDefault(); }
 
@@ -619,6 +640,28 @@ class ArnoldiEigenSolver {
     for (const auto& str : log_)
       if (str.compare(0, head.size(), head) == 0) ++count;
     return count;
+  }
+
+  // des(): eigen-decomposition of the current Hessenberg matrix without touching the solver's own state
+  ComplexVectorType hessenbergEigen_(ComplexMatrixType* vectors) const {
+    const MatrixType Hm = arnoldiBase_.makeHessenbergMatrix();
+    const int n = static_cast<int>(Hm.rows());
+    ComplexVectorType out(n);
+    if (vectors) vectors->resize(n, n);
+    if (n == 0) return out;
+    std::vector<small_eigen::cplx> H(static_cast<std::size_t>(n) * n), vals, vecs;
+    for (int c = 0; c < n; ++c)
+      for (int r = 0; r < n; ++r) H[static_cast<std::size_t>(r) + static_cast<std::size_t>(c) * n] = Hm(r, c);
+    small_eigen::hessenberg(H, n, vals, vectors ? &vecs : nullptr);
+    std::vector<std::size_t> order(static_cast<std::size_t>(n));
+    std::iota(order.begin(), order.end(), std::size_t(0));
+    std::stable_sort(order.begin(), order.end(), [&vals](std::size_t a, std::size_t b) { return std::abs(vals[a]) > std::abs(vals[b]); });
+    for (int i = 0; i < n; ++i) out[i] = vals[order[static_cast<std::size_t>(i)]];
+    if (vectors)
+      for (int c = 0; c < n; ++c)
+        std::copy(vecs.begin() + static_cast<std::ptrdiff_t>(order[static_cast<std::size_t>(c)]) * n,
+                  vecs.begin() + static_cast<std::ptrdiff_t>(order[static_cast<std::size_t>(c)] + 1) * n, vectors->colData(c));
+    return out;
   }
 
   // eigenvalues (and optionally eigenvectors) of the current Hessenberg matrix, sorted by

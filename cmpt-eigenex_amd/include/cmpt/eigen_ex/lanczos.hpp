@@ -114,6 +114,34 @@ struct HostOperatorThunk {
 // handle and mirrors what the device has computed.
 class KrylovDevice {
  public:
+  KrylovDevice() = default;
+  // copying a solver copies its Krylov state, as in the reference (implicitly copyable classes that own their
+  // vectors, lanczos.hpp:104-105): a device-to-device deep copy of the slab
+  KrylovDevice(const KrylovDevice& o) : ctx_(o.ctx_), n_global_(o.n_global_), row_begin_(o.row_begin_), n_rows_(o.n_rows_) {
+    if (o.basis_) device::check(eigenex_basis_clone(o.basis_, &basis_), "eigenex_basis_clone");
+  }
+  KrylovDevice& operator=(const KrylovDevice& o) {
+    if (this != &o) {
+      KrylovDevice tmp(o);
+      swap(tmp);
+    }
+    return *this;
+  }
+  KrylovDevice(KrylovDevice&& o) noexcept { swap(o); }
+  KrylovDevice& operator=(KrylovDevice&& o) noexcept {
+    if (this != &o) {
+      release();
+      swap(o);
+    }
+    return *this;
+  }
+  void swap(KrylovDevice& o) noexcept {
+    std::swap(ctx_, o.ctx_);
+    std::swap(basis_, o.basis_);
+    std::swap(n_global_, o.n_global_);
+    std::swap(row_begin_, o.row_begin_);
+    std::swap(n_rows_, o.n_rows_);
+  }
   ~KrylovDevice() { release(); }
   void release() {
     if (basis_) eigenex_basis_destroy(basis_);
@@ -304,8 +332,12 @@ class LanczosBase {
   const std::vector<RealScalar>& beta() const { return beta_; }
 
   LanczosBase() { setAllSettingsDefault(); }
-  LanczosBase(const LanczosBase&) = delete;
-  LanczosBase& operator=(const LanczosBase&) = delete;
+  // copyable and movable like the reference's class (implicit copy, lanczos.hpp:104-105): a copy owns a deep copy of
+  // the device state (basis slab, work vectors, coefficients) and can continue on its own
+  LanczosBase(const LanczosBase&) = default;
+  LanczosBase& operator=(const LanczosBase&) = default;
+  LanczosBase(LanczosBase&&) = default;
+  LanczosBase& operator=(LanczosBase&&) = default;
 
   // defaults of the reference (:260-271); does not clear computed data
   LanczosBase& setAllSettingsDefault() {
@@ -752,6 +784,24 @@ class LanczosEigenSolver {
     std::copy(vecs.begin(), vecs.end(), m.data());
     return m;
   }
+
+  // es_tri() (reference :646 returns its Eigen::SelfAdjointEigenSolver of the tridiagonal matrix): a view that answers
+  // the same questions about the CURRENT tridiagonal matrix -- eigenvalues() ascending, eigenvectors() column k for
+  // eigenvalue k, info() -- computed on demand by the library's own QL iteration
+  class TridiagonalSolverView {
+   public:
+    explicit TridiagonalSolverView(const LanczosEigenSolver* s) : s_(s) {}
+    RealVectorType eigenvalues() const {
+      const std::vector<RealScalar>& v = s_->tridiagonalEigenvalues();
+      return RealVectorType(v.data(), static_cast<Index>(v.size()));
+    }
+    RealMatrixType eigenvectors() const { return s_->tridiagonalEigenvectors(); }
+    ComputationInfo info() const { return ComputationInfo::Success; }
+
+   private:
+    const LanczosEigenSolver* s_;
+  };
+  TridiagonalSolverView es_tri() const { return TridiagonalSolverView(this); }
 
   // Eigen-style status (not in the reference; derived from the events it logs)
   ComputationInfo info() const { return info_; }

@@ -45,6 +45,7 @@ extern "C" {
 typedef struct eigenex_context_s* eigenex_context_t;
 typedef struct eigenex_csr_s* eigenex_csr_t;     /* device CSR operator (row shards + halo plan) */
 typedef struct eigenex_basis_s* eigenex_basis_t; /* Krylov state: basis slab V, work vectors, coefficients */
+typedef struct eigenex_plan_s* eigenex_plan_t;   /* host-only plan of one row shard (no GPU needed) */
 
 /* status codes */
 enum {
@@ -106,6 +107,40 @@ int eigenex_partition(int64_t n_global, int nshards, int shard, int64_t* begin, 
 int eigenex_halo_plan(int64_t n_global, int nshards, int shard, int64_t nnz, const int32_t* col_global,
                       int64_t* n_halo, int32_t* halo_cols, int64_t* count_per_owner /* nshards */);
 
+/* ---- shard plan on the host --------------------------------------------------
+ * The host-side half of eigenex_csr_upload, callable without a GPU: local/halo column numbering, receive segments,
+ * and -- once the owners have been told which rows are wanted (what exchange_send_lists_rccl ships over RCCL) -- the
+ * send segments.  The sharded upload runs exactly this code; tests/test_multirank_gloo.py drives it across real
+ * processes.  rowptr/col_global: the shard's rows as for eigenex_csr_upload (rowptr relative to the first row). */
+int eigenex_plan_create(int64_t n_global, int nshards, int shard, const int32_t* rowptr, const int32_t* col_global,
+                        eigenex_plan_t* out);
+int eigenex_plan_destroy(eigenex_plan_t plan);
+/* rows, padded rows (= index of the first halo slot), stored entries, halo slots, segments, rows to send (after the
+ * eigenex_plan_add_request calls); any pointer may be NULL */
+int eigenex_plan_sizes(eigenex_plan_t plan, int64_t* n_local, int64_t* n_pad, int64_t* nnz, int64_t* n_halo, int* n_recv,
+                       int* n_send, int64_t* n_send_rows);
+/* local column of every stored entry: [0, n_local) own rows, n_pad + s = halo slot s */
+int eigenex_plan_local_columns(eigenex_plan_t plan, int32_t* lcol);
+/* global column of every halo slot (ascending: grouped by owner) */
+int eigenex_plan_halo_columns(eigenex_plan_t plan, int32_t* cols_global);
+/* receive segment i: halo slots [offset[i], offset[i]+count[i]) come from shard peer[i]; the request to that owner is
+ * halo_columns[offset[i] .. offset[i]+count[i]) */
+int eigenex_plan_recv_segments(eigenex_plan_t plan, int32_t* peer, int64_t* offset, int64_t* count);
+/* install the request of shard `from_shard` (global row numbers this shard owns), in rank order as the upload does */
+int eigenex_plan_add_request(eigenex_plan_t plan, int from_shard, const int32_t* rows_global, int64_t count);
+/* send segment i: rows send_rows[offset[i] .. +count[i]) go to shard peer[i]; contig_start[i] >= 0 when they are the
+ * consecutive local rows contig_start[i].. (sent straight out of the vector, no pack kernel) */
+int eigenex_plan_send_segments(eigenex_plan_t plan, int32_t* peer, int64_t* offset, int64_t* count, int64_t* contig_start);
+int eigenex_plan_send_rows(eigenex_plan_t plan, int32_t* local_rows);
+
+/* Collectives that ONE call of the Lanczos step driver (eigenex_lanczos_enqueue) issues between shards, in order:
+ * ops[i] = EIGENEX_COLL_ALLREDUCE with counts[i] doubles, or EIGENEX_COLL_HALO (neighbour exchange of the operator
+ * input).  call_index counts calls since eigenex_basis_clear; *alpha_pending carries the state of the alpha fusion from
+ * call to call (start with 0).  Host only; a GPU test holds it against eigenex_context_trace of the real driver. */
+enum { EIGENEX_COLL_ALLREDUCE = 1, EIGENEX_COLL_HALO = 2 };
+int eigenex_lanczos_collectives(int call_index, int last_in_batch, int* alpha_pending, int64_t interval, int n_ortho,
+                                int ortho_mode, int alpha_fusion, int is_complex, int* ops, int* counts, int cap, int* n);
+
 /* ---- context ---------------------------------------------------------- */
 /* 128-byte RCCL unique id (rank 0 creates it, the host program broadcasts it). */
 int eigenex_rccl_unique_id(void* id128);
@@ -123,6 +158,10 @@ int eigenex_context_info(eigenex_context_t ctx, int* rank, int* world_size, int*
 /* what the RCCL communicator itself reports (ncclCommCount / ncclCommUserRank / ncclCommCuDevice): *comm_ranks = 0
  * when the context has no communicator (single GPU, loopback) */
 int eigenex_context_comm_info(eigenex_context_t ctx, int* comm_ranks, int* comm_rank, int* comm_device);
+/* record (on = 1: from now, forgetting earlier records) the collectives the step drivers enqueue on this context, and
+ * read the record back: same encoding as eigenex_lanczos_collectives */
+int eigenex_context_trace(eigenex_context_t ctx, int on);
+int eigenex_context_trace_get(eigenex_context_t ctx, int* ops, int* counts, int cap, int* n);
 /* the context's hipStream_t (as void*) */
 void* eigenex_context_stream(eigenex_context_t ctx);
 
@@ -199,6 +238,9 @@ int eigenex_basis_create_ex(eigenex_context_t ctx, eigenex_csr_t csr, int64_t n_
                             int is_complex, eigenex_basis_t* out);
 int eigenex_basis_is_complex(eigenex_basis_t b, int* is_complex);
 int eigenex_basis_destroy(eigenex_basis_t b);
+/* deep copy (same context, same operator handle): copying a solver object in the reference copies its vectors
+ * (implicitly copyable classes, lanczos.hpp:104-105, :233-239); device-to-device, synchronises */
+int eigenex_basis_clone(eigenex_basis_t src, eigenex_basis_t* out);
 int eigenex_basis_set_host_operator(eigenex_basis_t b, eigenex_matvec_fn fn, void* user);
 /* settings of LanczosBase/ArnoldiBase that the kernels need (lanczos.hpp:155-159) */
 int eigenex_basis_configure(eigenex_basis_t b, double eigenvalue_shift, double threshold,

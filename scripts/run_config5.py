@@ -21,39 +21,11 @@ N -= N % b
 nq = N // b
 
 
-def entry(i, j):
-    """symmetric in (i, j): a confining diagonal plus decaying couplings inside and between neighbouring sectors"""
-    d = np.abs(i - j)
-    off = 0.5 * np.cos(1.0e-3 * (i + j)) / (1.0 + d)
-    x = (i - 0.5 * N) * (64.0 / N)
-    return np.where(d == 0, x * x + 2.0, off)
-
+from cmpt_eigenex_amd import synthetic
 
 t0 = time.perf_counter()
-per = np.full(N, 3 * b, np.int64)
-per[:b] = 2 * b
-per[-b:] = 2 * b
-rowptr = np.zeros(N + 1, np.int64)
-np.cumsum(per, out=rowptr[1:])
-nnz = int(rowptr[-1])
-col = np.empty(nnz, np.int32)
-val = np.empty(nnz, np.float64)
-chunk = 2_000_000 - (2_000_000 % b)
-for r0 in range(0, N, chunk):
-    r1 = min(N, r0 + chunk)
-    i = np.arange(r0, r1, dtype=np.int64)
-    j = ((i // b - 1) * b)[:, None] + np.arange(3 * b, dtype=np.int64)[None, :]
-    ok = (j >= 0) & (j < N)
-    ii = np.broadcast_to(i[:, None], j.shape)[ok]
-    jj = j[ok]
-    col[rowptr[r0]:rowptr[r1]] = jj
-    val[rowptr[r0]:rowptr[r1]] = entry(ii, jj)
-# six isolated levels below the band (bound states of six "impurity" rows): the wanted lowest eigenpairs are well
-# separated relative to the spectral width (~1e3), so the thick-restart iteration converges in a few cycles
-for k, depth in enumerate((12.0, 11.0, 10.0, 9.0, 8.0, 7.0)):
-    i = (k + 1) * (N // 7)
-    p = rowptr[i] + int(np.flatnonzero(col[rowptr[i]:rowptr[i + 1]] == i)[0])
-    val[p] -= depth + (val[p] - 2.0)  # diagonal = 2 - depth
+Hm = synthetic.BlockHamiltonian(N, b)  # cmpt-eigenex_amd/synthetic.py: the generator the -m gpu test at N = 5e7 uses too
+rowptr, col, val, nnz = Hm.rowptr, Hm.col, Hm.val, Hm.nnz
 t_gen = time.perf_counter() - t0
 print(f"generated N={N} sectors={nq} (b={b}) nnz={nnz} in {t_gen:.1f} s", flush=True)
 
@@ -63,21 +35,9 @@ use_csr = "--csr" in sys.argv
 if use_csr:
     A = capi.Csr.upload(ctx, N, rowptr.astype(np.int32), col, val)
 else:
-    # the same entries as dense b x b blocks (q, q-1), (q, q), (q, q+1), column-major each: a row of the flattened
-    # matrix holds its blocks' rows side by side, so block (q, c) = val[rows of q, b columns] transposed
-    first, last = val[: b * 2 * b].reshape(b, 2, b), val[nnz - b * 2 * b:].reshape(b, 2, b)
-    mid = val[b * 2 * b: nnz - b * 2 * b].reshape(nq - 2, b, 3, b)  # [sector, row, block, column]
-    bl_mid = np.ascontiguousarray(mid.transpose(0, 2, 3, 1))          # [sector, block, column, row] = column-major blocks
-    bl_first = np.ascontiguousarray(first.transpose(1, 2, 0))
-    bl_last = np.ascontiguousarray(last.transpose(1, 2, 0))
-    values = np.concatenate([bl_first.ravel(), bl_mid.ravel(), bl_last.ravel()])
-    del mid, bl_mid
-    q_mid = np.repeat(np.arange(1, nq - 1, dtype=np.int64), 3)
-    qr_ = np.concatenate([[0, 0], q_mid, [nq - 1, nq - 1]])
-    qc_ = np.concatenate([[0, 1], q_mid + np.tile(np.array([-1, 0, 1], np.int64), nq - 2), [nq - 2, nq - 1]])
-    offsets = np.arange(qr_.size, dtype=np.int64) * (b * b)
-    sizes = np.full(nq, b, np.int64)
+    sizes, qr_, qc_, values, offsets = Hm.blocks()
     A = capi.Csr.upload_blocks_raw(ctx, sizes, sizes, qr_, qc_, values, offsets)
+    del values
 print(f"uploaded ({'CSR' if use_csr else 'dense blocks'}) in {time.perf_counter()-t0:.1f} s, stored entries {A.info()['nnz_local']}", flush=True)
 init = np.random.default_rng(5).standard_normal(N)
 es = solver.ThickRestartLanczosEigenSolver()

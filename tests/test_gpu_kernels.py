@@ -338,26 +338,33 @@ def test_ritz_vectors(capi, shards):
 
 def test_rccl_calls_on_single_rank_communicator(capi):
     """RCCL refuses two ranks on one device, so on a one-GPU box the RCCL transport is exercised on a
-    1-rank communicator: ncclCommInitRank, all-reduce, all-gather, grouped send/recv (to self), and a
-    Lanczos run whose three all-reduces per step go through ncclAllReduce on the library's stream."""
+    1-rank communicator: ncclCommInitRank, all-reduce, all-gather, grouped send/recv (to self), and Lanczos runs
+    whose all-reduces go through ncclAllReduce on the library's stream: two per step with the alpha fusion (the
+    default between ranks; the fused buffer [alpha, g, G] really crosses RCCL), three without."""
     ctx = capi.Context(rank=0, world_size=1, rccl_id=capi.rccl_unique_id())
     assert ctx.rccl_selftest()
+    assert ctx.comm_info()[0] == 1
     n, m = 12, 20
     N = n ** 3
     rowptr, col, val = cref.laplacian3d(n)
     init = np.random.default_rng(1).standard_normal(N)
     ref, ok = _lanczos_ref(rowptr, col, val, init, m + 1)
     A = capi.Csr.laplacian3d(ctx, n)
-    b = capi.Basis(ctx, A, N, m + 1)
-    b.upload(capi.VEC_W, init)
-    ctx.profile_enable(True)
-    b.lanczos_enqueue(m + 1)
-    st, alpha, beta = b.lanczos_state()
-    ctx.profile_enable(False)
-    assert st.nvec == m + 1
-    np.testing.assert_allclose(alpha, ref.alpha, atol=1e-12)
-    np.testing.assert_allclose(beta, ref.beta, atol=1e-12)
-    assert ctx.profile_get(capi.K_COMM)[0] >= 3 * m  # the collectives really ran
+    for fused, per_step in ((True, 2), (False, 3)):
+        b = capi.Basis(ctx, A, N, m + 1)
+        b.set_alpha_fusion(fused)
+        b.upload(capi.VEC_W, init)
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        b.lanczos_enqueue(m + 1)
+        st, alpha, beta = b.lanczos_state()
+        ctx.profile_enable(False)
+        assert st.nvec == m + 1 and st.nalpha == m + 1
+        np.testing.assert_allclose(alpha, ref.alpha, atol=1e-12)
+        np.testing.assert_allclose(beta, ref.beta, atol=1e-12)
+        ncomm = ctx.profile_get(capi.K_COMM)[0]  # the collectives really ran (no halo on one rank)
+        assert per_step * m <= ncomm <= per_step * m + 3, (fused, ncomm)
+        b.close()
     ctx.close()
 
 

@@ -629,3 +629,44 @@ def test_alpha_rides_on_the_dots_allreduce_between_shards(mods, shards):
     np.testing.assert_allclose(res[True][0], res[False][0], rtol=0, atol=1e-12)
     np.testing.assert_allclose(res[True][1], res[False][1], rtol=0, atol=1e-12)
     ctx.close()
+
+
+def test_collective_schedule_description_matches_the_driver(mods):
+    """eigenex_lanczos_collectives (host only; it steers the multi-process gloo test on CPU) against the collectives the
+    real step driver enqueues, recorded by eigenex_context_trace on the loopback transport: same kinds, same sizes, same
+    order, for every orthogonalisation scheme, with and without deflation vectors, strided re-orthogonalisation, alpha
+    fusion on and off, real and complex, across uneven enqueue batches."""
+    capi, _ = mods
+    n = 6
+    N = n ** 3
+    rowptr, col, val = cref.laplacian3d(n)
+    rng = np.random.default_rng(1)
+    ctx = capi.Context(loopback_shards=3)
+    for cplx in (False, True):
+        A = capi.Csr.upload(ctx, N, rowptr, col, val.astype(np.complex128) if cplx else val)
+        init = rng.standard_normal(N) + (1j * rng.standard_normal(N) if cplx else 0.0)
+        for mode in (capi.ORTHO_BATCHED, capi.ORTHO_SEQUENTIAL, capi.ORTHO_BATCHED_TWICE, capi.ORTHO_BATCHED_ADAPTIVE):
+            for interval, nq in ((1, 0), (1, 2), (3, 1), (0, 0)):
+                for fusion in (True, False):
+                    b = capi.Basis(ctx, A, N, 14, nq)
+                    b.configure(0.0, 1e-12, interval, mode)
+                    b.set_alpha_fusion(fusion)
+                    for q in range(nq):
+                        b.upload(capi.VEC_ORTHO(q), rng.standard_normal(N) + (1j * rng.standard_normal(N) if cplx else 0.0))
+                    b.upload(capi.VEC_W, init)
+                    call, pending = 0, False
+                    for batch in (1, 4, 2, 6):
+                        want = []
+                        for i in range(batch):
+                            ops, pending = capi.lanczos_collectives(call, i == batch - 1, pending, interval, nq, mode, fusion, cplx)
+                            want += ops
+                            call += 1
+                        ctx.trace(True)
+                        b.lanczos_enqueue(batch)
+                        b.lanczos_state()
+                        ctx.trace(False)
+                        assert ctx.trace_get() == want, (cplx, mode, interval, nq, fusion, call)
+                        assert not pending  # every batch closes its own alpha
+                    b.close()
+        A.close()
+    ctx.close()

@@ -522,3 +522,18 @@ def test_cpp_program_block_operator(tmp_path):
         assert np.abs(H @ X - X * np.array(r["eigenvalues"])).max() < 1e-8
     # same sums in both formats (bit-identical operator output, same 256-row partial dots)
     assert out["blocks"]["eigenvalues"] == out["csr"]["eigenvalues"] and out["blocks"]["restarts"] == out["csr"]["restarts"]
+
+
+def test_cpp_program_copy_semantics_and_small_solver_views(tmp_path):
+    """C++ user program: solver objects copy and move like the reference's (deep copy of the device state, reference
+    lanczos.hpp:104-105), a copy continues independently with bit-identical results; es_tri() / des() views (reference
+    lanczos.hpp:646, arnoldi.hpp:670)."""
+    exe = str(tmp_path / "copy_semantics_amd")
+    lib = os.path.join(ROOT, "cmpt-eigenex_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-I", os.path.join(ROOT, "include"), "-I",
+                           os.path.join(ROOT, "cmpt-eigenex_amd", "include"),
+                           os.path.join(ROOT, "tests", "cpp", "copy_semantics_amd.cpp"), "-o", exe, "-L", lib,
+                           "-leigenex_hip", "-Wl,-rpath," + lib])
+    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0, (out.stdout + out.stderr).decode()[-3000:]
+    assert b"all checks passed" in out.stdout
