@@ -116,6 +116,7 @@ SIGNATURES = {
     "eigenex_lanczos_enqueue": (C.c_int, [_vp, C.c_int]),
     "eigenex_basis_set_alpha_fusion": (C.c_int, [_vp, C.c_int]),
     "eigenex_basis_clone": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "eigenex_basis_graph_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "eigenex_arnoldi_enqueue": (C.c_int, [_vp, C.c_int]),
     "eigenex_lanczos_restart": (C.c_int, [_vp, C.c_int, _dp, C.c_int, C.c_double]),
     "eigenex_lanczos_state": (C.c_int, [_vp, C.POINTER(State), _dp, _dp]),
@@ -524,6 +525,11 @@ class Basis:
 
     def tune(self, vec_blocks_per_cu=2, spmv_blocks_per_cu=4, flags=0):
         _chk(lib().eigenex_basis_tune(self.h, vec_blocks_per_cu, spmv_blocks_per_cu, flags))
+
+    def graph_info(self):
+        n, t, lim = C.c_int(), C.c_int64(), C.c_int64()
+        _chk(lib().eigenex_basis_graph_info(self.h, C.byref(n), C.byref(t), C.byref(lim)))
+        return dict(graphs=n.value, nodes=t.value, node_limit=lim.value)
 
     def set_alpha_fusion(self, on: bool):
         _chk(lib().eigenex_basis_set_alpha_fusion(self.h, int(bool(on))))

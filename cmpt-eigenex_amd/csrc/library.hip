@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <pthread.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -247,6 +249,7 @@ struct StepGraph {
   bool started_after = false;
   int h_nvec_after = 0;
   uint64_t last_use = 0;
+  int64_t nodes = 0;
 };
 
 struct eigenex_basis_s {
@@ -1133,8 +1136,50 @@ int arnoldi_call(eigenex_basis_s* b) {
 // no longer prepares ~6 launches per step.  Anything that changes what a launch would look like is part of the key.
 constexpr int kMaxStepGraphs = 8;
 constexpr int kMinGraphCalls = 4;
-constexpr int kMaxGraphCalls = 256;  // x (6..20 launches per call) nodes; the sequential scheme (2j launches per call) is never recorded:
-                                     // a batch of 301 such calls (1.8e5 nodes) crashed the runtime inside the capture
+// Size limit of a recorded batch, in graph NODES.  Cause of round 1's crash (a 301-call batch of the sequential scheme,
+// ~1.8e5 launches), found with scripts/microbench/graph_chain.hip (profiles/r02_graph_chain.md): hipGraphInstantiate
+// walks a linear chain of kernel nodes recursively and overflows the calling thread's stack -- 120,000 nodes pass and
+// 180,000 die with SIGSEGV inside hipGraphInstantiate on the default 8 MiB stack, the same 180,000 pass with
+// `ulimit -s unlimited` or 256 MiB: 47..70 bytes of stack per node.  Capture and hipStreamEndCapture are not affected.
+// So the limit follows the stack that is actually left on the calling thread, at 512 bytes per node (a 7x margin),
+// and never exceeds kMaxGraphNodes; a batch whose upper bound of launches is above it is run as plain launches before
+// anything is captured.
+constexpr int64_t kMaxGraphNodes = 20000;
+constexpr int64_t kStackBytesPerGraphNode = 512;
+
+int64_t stack_room_bytes() {
+  pthread_attr_t attr;
+  if (pthread_getattr_np(pthread_self(), &attr) != 0) return 1 << 20;
+  void* base = nullptr;
+  size_t size = 0;
+  const int rc = pthread_attr_getstack(&attr, &base, &size);
+  pthread_attr_destroy(&attr);
+  if (rc != 0 || !base) return 1 << 20;
+  char here;
+  const char* lo = static_cast<const char*>(base);
+  const int64_t room = &here - lo;  // the stack grows down towards `base`
+  return room > 0 && room <= (int64_t)size ? room : 1 << 20;
+}
+
+int64_t graph_node_limit() { return std::min<int64_t>(kMaxGraphNodes, stack_room_bytes() / kStackBytesPerGraphNode); }
+
+// upper bound of the launches (kernels, copies, memsets) that `ncalls` step calls enqueue from the current state
+int64_t launches_upper_bound(const eigenex_basis_s* b, int ncalls) {
+  int passes = 1;
+  if (b->csr)
+    for (auto& s : b->csr->sh) passes = std::max(passes, s.passes);
+  int64_t total = 0;
+  int nvec = b->h_nvec;
+  for (int i = 0; i < ncalls; ++i) {
+    const int64_t cols = (int64_t)nvec + b->nq + 1;
+    const int64_t dots_chunks = cols * b->es * 2 / kDotsMaxAcc + 1;
+    int64_t per = 24 + 2 * passes + 4 * dots_chunks;  // batched / twice / adaptive: <= 2 passes of dots+reduce+update+reduce, finalisers, operator
+    if (b->ortho_mode == EIGENEX_ORTHO_SEQUENTIAL) per += 4 * cols;  // dot, reduce, update (+ reduce) per vector
+    total += per;
+    if (nvec < b->cap) ++nvec;
+  }
+  return total;
+}
 
 void drop_step_graphs(eigenex_basis_s* b) {
   for (auto& g : b->graphs)
@@ -1149,8 +1194,8 @@ int enqueue_steps(eigenex_basis_s* b, int ncalls, int kind) {
   };
   eigenex_context_s* c = b->ctx;
   static const bool graphs_on = std::getenv("EIGENEX_NO_GRAPHS") == nullptr;
-  if (!graphs_on || !b->csr || c->comm || b->sh.size() != 1 || c->profiling || ncalls < kMinGraphCalls || ncalls > kMaxGraphCalls ||
-      b->ortho_mode == EIGENEX_ORTHO_SEQUENTIAL)
+  if (!graphs_on || !b->csr || c->comm || b->sh.size() != 1 || c->profiling || c->tracing || ncalls < kMinGraphCalls ||
+      launches_upper_bound(b, ncalls) > graph_node_limit())
     return plain();  // (the loopback transport multiplies the launches by its shard count and is for verification anyway)
   StepGraphKey key;
   std::memset(&key, 0, sizeof(key));
@@ -1177,7 +1222,11 @@ int enqueue_steps(eigenex_basis_s* b, int ncalls, int kind) {
   hipGraph_t graph = nullptr;
   const hipError_t ec = hipStreamEndCapture(c->stream, &graph);
   hipGraphExec_t exec = nullptr;
-  if (rc == 0 && ec == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+  size_t nodes = 0;
+  // second guard behind the upper bound: count what was really captured (not recursive) before instantiating
+  const bool small_enough = rc == 0 && ec == hipSuccess && graph && hipGraphGetNodes(graph, nullptr, &nodes) == hipSuccess &&
+                            (int64_t)nodes <= graph_node_limit();
+  if (small_enough && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
     (void)hipGraphDestroy(graph);
     if ((int)b->graphs.size() >= kMaxStepGraphs) {  // evict the least recently used
       size_t victim = 0;
@@ -1187,6 +1236,7 @@ int enqueue_steps(eigenex_basis_s* b, int ncalls, int kind) {
       b->graphs.erase(b->graphs.begin() + (std::ptrdiff_t)victim);
     }
     StepGraph g;
+    g.nodes = (int64_t)nodes;
     g.key = key, g.exec = exec, g.started_after = b->started, g.h_nvec_after = b->h_nvec, g.last_use = ++b->graph_clock;
     b->graphs.push_back(g);
     HIPCHK(hipGraphLaunch(exec, c->stream));
@@ -2186,6 +2236,16 @@ int eigenex_basis_clear(eigenex_basis_t b) {
   b->started = false;
   b->h_nvec = 0;
   b->alpha_pending = false;
+  return 0;
+}
+
+int eigenex_basis_graph_info(eigenex_basis_t b, int* ngraphs, int64_t* nodes_total, int64_t* node_limit) {
+  if (!b) return fail(EIGENEX_ERR_ARG, "basis is NULL");
+  int64_t t = 0;
+  for (auto& g : b->graphs) t += g.nodes;
+  if (ngraphs) *ngraphs = (int)b->graphs.size();
+  if (nodes_total) *nodes_total = t;
+  if (node_limit) *node_limit = graph_node_limit();
   return 0;
 }
 

@@ -267,6 +267,10 @@ int eigenex_basis_clear(eigenex_basis_t b);
  * V^H u_{k+1}, from which h = V^H w0 is formed exactly): 2 instead of 3 all-reduces per step, results equal to rounding.
  * on = 0 restores one all-reduce per scalar.  Single-shard contexts are not affected. */
 int eigenex_basis_set_alpha_fusion(eigenex_basis_t b, int on);
+/* Recorded step batches (hipGraphs) of this state: how many are cached, their node count, and the node limit that applies
+ * on the calling thread (hipGraphInstantiate recurses over a linear chain: the limit follows the stack that is left, see
+ * library.hip).  Batches above the limit run as plain launches. */
+int eigenex_basis_graph_info(eigenex_basis_t b, int* ngraphs, int64_t* nodes_total, int64_t* node_limit);
 
 /* host <-> device vectors (rows owned by this context) */
 int eigenex_vec_upload(eigenex_basis_t b, int vec_ref, const double* host);

@@ -513,11 +513,13 @@ def test_replayed_step_graph_with_new_start_vectors(mods):
     ctx.close()
 
 
-def test_large_batches_and_sequential_scheme_are_not_recorded_as_graphs(mods):
-    """Regression: a batch of 301 step calls under the sequential Gram-Schmidt scheme is ~1.8e5 launches; recording
-    it as a hipGraph crashed the runtime.  Such batches (sequential scheme, or more than 256 calls) run as plain
-    launches; deflation vectors that are not invariant under the operator stay orthogonal to the basis in every
-    scheme."""
+def test_recorded_batches_are_bounded_by_graph_nodes(mods):
+    """Round 1's crash, explained (scripts/microbench/graph_chain.hip, profiles/r02_graph_chain.md): hipGraphInstantiate
+    recurses over a linear chain of kernel nodes and overflowed the 8 MiB stack at ~1.8e5 nodes -- the 301-call batch of
+    the sequential Gram-Schmidt scheme.  Recording is now bounded by NODES (upper bound of launches before capturing,
+    real count before instantiating, limit derived from the stack left on the calling thread): the big sequential
+    batch runs as plain launches, a small sequential batch and a long batched one are recorded and replay bit for bit.
+    Deflation vectors that are not invariant under the operator stay orthogonal to the basis in every scheme."""
     capi, solver = mods
     n, m, nq = 16, 300, 3
     N = n ** 3
@@ -537,6 +539,19 @@ def test_large_batches_and_sequential_scheme_are_not_recorded_as_graphs(mods):
         b.lanczos_enqueue(m + 1)
         st, al, be = b.lanczos_state()
         assert st.nvec == m + 1
+        gi = b.graph_info()
+        assert 1000 <= gi["node_limit"] <= 20000
+        if mode == 1:  # ~2 * 301 * 300 launches: far above any limit, must not have been captured
+            assert gi["graphs"] == 0
+        else:  # 301 calls of <= ~12 launches
+            assert gi["graphs"] == 1 and 301 * 5 <= gi["nodes"] <= gi["node_limit"]
+            b.clear()
+            b.upload(capi.VEC_W, init)
+            b.lanczos_enqueue(m + 1)  # replay
+            _, al2, be2 = b.lanczos_state()
+            np.testing.assert_array_equal(al2, al)
+            np.testing.assert_array_equal(be2, be)
+            assert b.graph_info()["graphs"] == 1
         idx = np.arange(0, m + 1, 25)
         G = np.stack([b.dots(capi.VEC_COL(int(c)), 0, 1, m + 1, n_ortho_used=nq) for c in idx])
         GV = G[:, : m + 1].copy()
@@ -544,6 +559,20 @@ def test_large_batches_and_sequential_scheme_are_not_recorded_as_graphs(mods):
         assert np.abs(GV).max() < 1e-13 and np.abs(G[:, m + 1:]).max() < 1e-13
         alphas.append(ko.tridiagonal_eigh(al, be, vectors=False)[0])
         b.close()
+    # a SMALL batch of the sequential scheme is recorded now (it used to be excluded wholesale)
+    b = capi.Basis(ctx, A, N, 25)
+    b.configure(ortho_mode=1)
+    runs = []
+    for rep in range(2):
+        b.clear()
+        b.upload(capi.VEC_W, init)
+        b.lanczos_enqueue(24)
+        runs.append(b.lanczos_state()[1:])
+    gi = b.graph_info()
+    assert gi["graphs"] == 1 and gi["nodes"] > 24 * 12
+    np.testing.assert_array_equal(runs[0][0], runs[1][0])
+    np.testing.assert_array_equal(runs[0][1], runs[1][1])
+    b.close()
     # alpha/beta of late steps are not comparable between schemes (rounding is amplified once Ritz values have
     # converged); the converged ends of the spectrum are
     for th in (alphas[0], alphas[2]):
