@@ -88,6 +88,7 @@ SIGNATURES = {
     "eigenex_csr_destroy": (C.c_int, [_vp]),
     "eigenex_csr_upload_ex": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int64, _ip, _ip, _dp, C.c_int, C.c_int, C.POINTER(_vp)]),
     "eigenex_csr_column_blocks": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "eigenex_csr_layout": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "eigenex_csr_upload_device": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, C.c_int, C.POINTER(_vp)]),
     "eigenex_block_upload": (C.c_int, [_vp, C.c_int64, C.c_int, _lp, C.c_int, _lp, C.c_int64, _lp, _lp, C.POINTER(C.c_void_p), C.POINTER(_vp)]),
     "eigenex_block_upload_z": (C.c_int, [_vp, C.c_int64, C.c_int, _lp, C.c_int, _lp, C.c_int64, _lp, _lp, C.POINTER(C.c_void_p), C.POINTER(_vp)]),
@@ -459,6 +460,11 @@ class Csr:
         h = _vp()
         _chk(lib().eigenex_csr_laplacian3d(ctx.h, n, C.byref(h)))
         return cls(ctx, h)
+
+    def layout(self) -> str:
+        v = C.c_int()
+        _chk(lib().eigenex_csr_layout(self.h, C.byref(v)))
+        return ("csr", "column_blocked", "sorted_tiles", "dense_blocks")[v.value]
 
     def column_blocks(self) -> int:
         k = C.c_int()

@@ -532,6 +532,158 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int32_t* __restrict__ row
   }
 }
 
+// ---------------------------------------------------------------------------
+// CSR SpMV for operators whose gathers are scattered over an input larger than L2 (BASELINE config 3: 10^6 rows,
+// 32 random columns each), "column-sorted row tiles".  Measured on the stream form above (rocprofv3 PMC,
+// profiles/r02_config3_pmc.md): every gather is its own L2 request (8.8e6 TCP->TCC reads for 8.0e6 gathers per
+// pass, L2 hit rate 0.88), the L1s wait on their pending-request limit 72 % of the time, 296 cycles per request: the
+// pass is bound by L2 REQUESTS, not bytes.  The only lever is fewer requests per gather, i.e. lanes of one wave
+// hitting the same 128-byte line -- which needs (a) many gathers per input line inside one workgroup's working set and
+// (b) visiting them in column order.  So:
+//   * a workgroup of 1024 threads owns a tile of 4096 rows and walks the K column slices (<= 256 KB of input each,
+//     L2-resident; all workgroups are in the same slice at about the same time) INSIDE the kernel, row sums in
+//     registers: no carry through memory between slices;
+//   * the entries of one (tile, slice) -- ~4096 on config 3, 2 per input line -- are STORED sorted by column
+//     (col, val, and a 16-bit slot = position of the entry in row order), so consecutive lanes gather from the same
+//     or neighbouring lines; products are scattered into LDS by slot (index skewed like above);
+//   * row phase: every thread adds the products of its 4 rows in stored order, slice after slice = the stored
+//     order of the row when its columns ascend: still bit-identical to the oracle's row loop.
+// Gather skeleton (scripts/microbench/gather_sorted.hip): 168-196 G gathers/s in row order, 255-288 sorted.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum16(double x, double* lds16) {
+  x = wave_sum(x);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) lds16[wave] = x;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int w = 0; w < kSortBlock / 64; ++w) t += lds16[w];
+  return t;
+}
+
+// entries of one segment held in registers between the loads and their use: two rounds of 4 per lane (<= 8192 entries)
+struct SortedRegs {
+  int4 ca, cb;
+  double2 a01, a23, b01, b23;
+  ushort4 pa, pb;
+  bool in0, in1;
+};
+struct SortedX {
+  double a0, a1, a2, a3, b0, b1, b2, b3;
+};
+__device__ __forceinline__ void sorted_load(SortedRegs& g, const SortedOperatorView& op, int e0, int e1, int tid) {
+  const int q0 = e0 + 4 * tid, q1 = q0 + 4 * kSortBlock;
+  g.in0 = q0 < e1, g.in1 = q1 < e1;
+  if (g.in0) {
+    g.ca = *reinterpret_cast<const int4*>(op.col + q0);
+    g.a01 = ld2(op.val + q0);
+    g.a23 = ld2(op.val + q0 + 2);
+    g.pa = *reinterpret_cast<const ushort4*>(op.pos + q0);
+  }
+  if (g.in1) {
+    g.cb = *reinterpret_cast<const int4*>(op.col + q1);
+    g.b01 = ld2(op.val + q1);
+    g.b23 = ld2(op.val + q1 + 2);
+    g.pb = *reinterpret_cast<const ushort4*>(op.pos + q1);
+  }
+}
+__device__ __forceinline__ void sorted_gather(SortedX& x, const SortedRegs& g, const double* __restrict__ x_ext) {
+  x.a0 = x.a1 = x.a2 = x.a3 = x.b0 = x.b1 = x.b2 = x.b3 = 0.0;
+  if (g.in0) x.a0 = x_ext[g.ca.x], x.a1 = x_ext[g.ca.y], x.a2 = x_ext[g.ca.z], x.a3 = x_ext[g.ca.w];  // all eight in flight
+  if (g.in1) x.b0 = x_ext[g.cb.x], x.b1 = x_ext[g.cb.y], x.b2 = x_ext[g.cb.z], x.b3 = x_ext[g.cb.w];
+}
+__device__ __forceinline__ void sorted_scatter(const SortedRegs& g, const SortedX& x, double scale, double* prod) {
+  if (g.in0) {
+    prod[skew(g.pa.x)] = g.a01.x * (x.a0 * scale);
+    prod[skew(g.pa.y)] = g.a01.y * (x.a1 * scale);
+    prod[skew(g.pa.z)] = g.a23.x * (x.a2 * scale);
+    prod[skew(g.pa.w)] = g.a23.y * (x.a3 * scale);
+  }
+  if (g.in1) {
+    prod[skew(g.pb.x)] = g.b01.x * (x.b0 * scale);
+    prod[skew(g.pb.y)] = g.b01.y * (x.b1 * scale);
+    prod[skew(g.pb.z)] = g.b23.x * (x.b2 * scale);
+    prod[skew(g.pb.w)] = g.b23.y * (x.b3 * scale);
+  }
+}
+
+// RPT = rows per thread = tile rows / 1024: a thread owns RPT CONSECUTIVE rows (their RPT+1 slot offsets are adjacent
+// 16-bit values, their outputs one or two 16-byte stores)
+template <int RPT>
+__global__ __launch_bounds__(kSortBlock) void k_spmv_sorted(SortedOperatorView op, const double* __restrict__ x_ext,
+                                                            const double* __restrict__ scale_ptr, double shift,
+                                                            double* __restrict__ y, double* __restrict__ u_out, int64_t n,
+                                                            int64_t ntiles, double* __restrict__ partials, int pass,
+                                                            const Ctrl* __restrict__ ctrl) {
+  extern __shared__ double lds_prod[];  // two buffers of kSortBufDoubles
+  __shared__ double lds16[kSortBlock / 64];
+  if (ctrl->stopped) return;
+  const double scale = scale_ptr ? *scale_ptr : 1.0;
+  const int tid = threadIdx.x;
+  const int K = op.nslices;
+  constexpr int T = RPT * kSortBlock;
+  double dot = 0.0;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t r0 = tile * T + (int64_t)tid * RPT;  // first row of this thread
+    const int32_t* tb = op.base + tile * (K + 1);
+    double sum[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) sum[i] = 0.0;
+    // Pipeline over the slices, ONE barrier per segment: while the row phase of segment k runs, the gathers of segment
+    // k+1 are in flight and its products go to the other LDS buffer; the entry streams run one segment ahead.  (A
+    // deeper pipeline -- column indices two segments ahead -- was measured slower: 213 vs 199 us, 126 VGPRs.)
+    SortedRegs g, gn;
+    SortedX x;
+    unsigned short o[RPT + 1], on[RPT + 1];
+    auto load_offsets = [&](unsigned short (&dst)[RPT + 1], int k) {
+      const uint16_t* p = op.off + (tile * K + k) * (int64_t)(T + 1) + tid * RPT;
+#pragma unroll
+      for (int i = 0; i <= RPT; ++i) dst[i] = p[i];
+    };
+    sorted_load(g, op, tb[0], tb[1], tid);
+    load_offsets(o, 0);
+    sorted_gather(x, g, x_ext);
+    for (int k = 0; k < K; ++k) {
+      double* prod = lds_prod + (k & 1) * kSortBufDoubles;
+      if (k + 1 < K) {  // (a) entry streams and offsets of the next segment
+        sorted_load(gn, op, tb[k + 1], tb[k + 2], tid);
+        load_offsets(on, k + 1);
+      }
+      sorted_scatter(g, x, scale, prod);  // (b) products of segment k (waits for its gathers)
+      __syncthreads();                    // (c) the only barrier: buffer k&1 complete; buffer (k+1)&1 free since the last one
+      if (k + 1 < K) sorted_gather(x, gn, x_ext);  // (d) gathers of segment k+1 fly during the row phase
+      // (e) row phase: stored order within the slice, multiply-then-add.  (Reading a thread's first 8 slots with
+      // independent LDS loads and handing them to the rows by compares was measured slower: 184 vs 171 us.)
+#pragma unroll
+      for (int i = 0; i < RPT; ++i)
+        for (int t = o[i]; t < o[i + 1]; ++t) sum[i] = sum[i] + prod[skew(t)];
+      if (k + 1 < K) {
+        g = gn;
+#pragma unroll
+        for (int i = 0; i <= RPT; ++i) o[i] = on[i];
+      }
+    }
+    __syncthreads();  // the next tile's first scatter reuses buffer 0
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int64_t r = r0 + i;
+      if (r < n) {
+        const double xr = x_ext[r] * scale;
+        double yr = sum[i];
+        if (shift != 0.0) yr = add_product_nofma(yr, shift, xr);  // lanczos.hpp:390-392
+        y[r] = yr;
+        if (u_out) u_out[r] = xr;
+        dot = (pass & kPassSelfNorm) ? fma(yr, yr, dot) : fma(xr, yr, dot);
+      }
+    }
+  }
+  if (partials) {
+    dot = block_sum16(dot, lds16);
+    if (tid == 0) partials[blockIdx.x] = dot;
+  }
+}
+
 // Complex fp64 variant (the scalar type of the reference's own samples): entries, x and
 // products are 16-byte (re, im) pairs; 1024 products per LDS chunk.  Same two phases, same
 // stored-order accumulation; products use separate multiplies and adds (no contraction),
@@ -1297,6 +1449,29 @@ void launch_spmv(hipStream_t s, const int32_t* rowptr, const int32_t* col, const
   hipLaunchKernelGGL(k_spmv, dim3(grid), dim3(kBlock), 0, s, rowptr, col, val, x_ext, scale, shift, y, u_out, n,
                      ntiles, partials, spmv_flags, pass, ctrl);
 }
+
+void launch_spmv_sorted(hipStream_t s, const SortedOperatorView& op, const double* x_ext, const double* scale, double shift, double* y,
+                        double* u_out, int64_t n, double* partials, const Ctrl* ctrl, int pass) {
+  const size_t shmem = sizeof(double) * 2 * kSortBufDoubles;
+  static const bool attr_set = [shmem] {
+    bool ok = true;
+    ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmv_sorted<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) == hipSuccess;
+    ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmv_sorted<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) == hipSuccess;
+    ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmv_sorted<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) == hipSuccess;
+    return ok;
+  }();
+  (void)attr_set;
+  const int64_t ntiles = (n + op.tile_rows - 1) / op.tile_rows;
+  const dim3 grid(sorted_grid(n, op.tile_rows)), block(kSortBlock);
+  if (op.tile_rows == 4 * kSortBlock)
+    hipLaunchKernelGGL(k_spmv_sorted<4>, grid, block, shmem, s, op, x_ext, scale, shift, y, u_out, n, ntiles, partials, pass, ctrl);
+  else if (op.tile_rows == 2 * kSortBlock)
+    hipLaunchKernelGGL(k_spmv_sorted<2>, grid, block, shmem, s, op, x_ext, scale, shift, y, u_out, n, ntiles, partials, pass, ctrl);
+  else
+    hipLaunchKernelGGL(k_spmv_sorted<1>, grid, block, shmem, s, op, x_ext, scale, shift, y, u_out, n, ntiles, partials, pass, ctrl);
+}
+
+int sorted_grid(int64_t n, int tile_rows) { return grid_for_tiles((n + tile_rows - 1) / tile_rows, 1); }
 
 void launch_block_spmv(hipStream_t s, const BlockOperatorView& op, const double* x_ext, const double* scale, double shift,
                        double* y, double* u_out, int64_t n, double* partials, int grid, const Ctrl* ctrl, int pass) {

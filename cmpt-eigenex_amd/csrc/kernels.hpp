@@ -73,6 +73,28 @@ enum { kPassCarry = 1, kPassNotLast = 2, kPassSelfNorm = 4 };
 void launch_spmv(hipStream_t s, const int32_t* rowptr, const int32_t* col, const double* val, const double* x_ext,
                  const double* scale, double shift, double* y, double* u_out, int64_t n, double* partials, int grid,
                  const Ctrl* ctrl, int spmv_flags = 0, int pass = 0);
+// Column-sorted row tiles (real fp64; kernels.hip: k_spmv_sorted): tile t = rows [t*T, (t+1)*T), T = tile_rows, slice k =
+// the k-th range of the operator input (global column order).  Segment (t, k) = entries base[t*(K+1)+k] .. base[t*(K+1)+k+1)
+// of col/val/pos, sorted by column, padded to a multiple of 4 (val 0, a spare slot); pos = slot of the entry in row order
+// inside the segment; off[(t*K+k)*(T+1) + i] = first slot of row i of the tile (so a row's products are added
+// in stored order).  At most kSortCap - 4 entries per segment.
+constexpr int kSortRows = 4096;
+constexpr int kSortBlock = 1024;
+constexpr int kSortCap = 8192;            // entries of one segment (two rounds of 4 per lane); two LDS buffers of this size
+constexpr int kSortBufDoubles = kSortCap + kSortCap / 32 + 8;
+constexpr int kSortSliceElems = 32768;    // <= 256 KB of fp64 input per slice
+struct SortedOperatorView {
+  const int32_t* base;
+  const int32_t* col;
+  const double* val;
+  const uint16_t* pos;
+  const uint16_t* off;
+  int nslices;
+  int tile_rows;  // 4096, 2048 or 1024: the largest for which every segment fits the product buffer
+};
+int sorted_grid(int64_t n, int tile_rows);
+void launch_spmv_sorted(hipStream_t s, const SortedOperatorView& op, const double* x_ext, const double* scale, double shift, double* y,
+                        double* u_out, int64_t n, double* partials, const Ctrl* ctrl, int pass = 0);
 // Block-sparse operator (the reference's BlockTensor<Scalar,2> layout, block_tensor.hpp:1193-1206, real or complex fp64):
 // 8 bytes per stored entry plus one column index per block COLUMN (4/rows bytes per entry) instead of CSR's 12.
 //   group g = the rows of one sector that this shard owns, rows grow0[g] .. grow0[g+1].  Its blocks, side by side,

@@ -194,6 +194,12 @@ struct CsrShard {
   int32_t* rowptr = nullptr;
   int32_t* col = nullptr;
   double* val = nullptr;
+  // column-sorted row tiles (kernels.hpp: SortedOperatorView) instead of rowptr/col/val: scattered gathers over an input
+  // larger than L2 (see build_sorted_layout)
+  bool sorted = false;
+  int nslices = 0, tile_rows = 0;
+  int32_t* s_base = nullptr;
+  uint16_t *s_pos = nullptr, *s_off = nullptr;
   // block-sparse format (eigenex_block_upload; kernels.hpp: BlockOperatorView) instead of rowptr/col/val
   bool blocked = false;
   double* bval = nullptr;
@@ -358,7 +364,8 @@ void free_csr_shard(CsrShard& s) {
   if (s.val) (void)hipFree(s.val);
   if (s.send_idx) (void)hipFree(s.send_idx);
   if (s.sendbuf) (void)hipFree(s.sendbuf);
-  for (void* p : {(void*)s.bval, (void*)s.gent, (void*)s.gcol, (void*)s.cols, (void*)s.grow0, (void*)s.rowgrp})
+  for (void* p : {(void*)s.bval, (void*)s.gent, (void*)s.gcol, (void*)s.cols, (void*)s.grow0, (void*)s.rowgrp, (void*)s.s_base,
+                  (void*)s.s_pos, (void*)s.s_off})
     if (p) (void)hipFree(p);
   s = CsrShard();
 }
@@ -462,6 +469,124 @@ int choose_column_blocks(const CsrShard& s, const std::vector<int32_t>& lcol, co
   return K;
 }
 
+template <class T>
+int upload_vec(eigenex_context_s* c, T** dev, const std::vector<T>& host, size_t extra = 0) {
+  HIPCHK(hipMalloc(dev, sizeof(T) * (host.size() + extra + 1)));
+  HIPCHK(hipMemsetAsync(*dev, 0, sizeof(T) * (host.size() + extra + 1), c->stream));
+  if (!host.empty()) HIPCHK(hipMemcpyAsync(*dev, host.data(), sizeof(T) * host.size(), hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+
+// position of a local column index in GLOBAL column order (halo columns below the shard, own rows, halo columns above):
+// slices of the operator input are cut along this order so that a row with ascending global columns meets them in order
+struct GlobalOrder {
+  int64_t n_low, npad, nloc;
+  explicit GlobalOrder(const CsrShard& s)
+      : n_low(std::lower_bound(s.halo_cols.begin(), s.halo_cols.end(), (int32_t)std::min<int64_t>(s.rb, 2147483647)) - s.halo_cols.begin()),
+        npad(s.npad), nloc(s.nloc) {}
+  int64_t operator()(int64_t lc) const {
+    if (lc < npad) return n_low + lc;
+    const int64_t h = lc - npad;
+    return h < n_low ? h : nloc + h;
+  }
+};
+
+// are the gathers of this shard scattered (>= 0.5 distinct 128-byte input lines per stored entry in sampled 256-row tiles)?
+bool gathers_scattered(const CsrShard& s, const std::vector<int32_t>& lcol, const std::vector<int32_t>& lrp) {
+  int64_t entries = 0, lines = 0;
+  std::vector<int32_t> tmp;
+  for (int64_t r0 = 0; r0 < s.nloc; r0 += 256 * 61) {
+    const int64_t r1 = std::min<int64_t>(r0 + 256, s.nloc);
+    tmp.assign(lcol.begin() + lrp[r0], lcol.begin() + lrp[r1]);
+    for (auto& x : tmp) x = (int32_t)(((int64_t)x * s.es) >> 4);
+    std::sort(tmp.begin(), tmp.end());
+    entries += (int64_t)tmp.size();
+    lines += std::unique(tmp.begin(), tmp.end()) - tmp.begin();
+  }
+  return entries > 0 && 2 * lines >= entries;
+}
+
+// Column-sorted row tiles (kernels.hip: k_spmv_sorted).  Eligible when the operator is real, every row meets the slices in
+// stored order (so the result stays bit-identical to the row loop), a (tile, slice) segment fits the LDS product buffer
+// and the slice count stays small.  Returns false (nothing built) otherwise.
+struct SortedLayout {
+  int K = 0, T = 0;
+  std::vector<int32_t> base, col;
+  std::vector<double> val;
+  std::vector<uint16_t> pos, off;
+};
+bool build_sorted_layout_t(const CsrShard& s, const std::vector<int32_t>& lcol, const std::vector<int32_t>& lrp, const double* vsrc,
+                           SortedLayout& L, int T);
+bool build_sorted_layout(const CsrShard& s, const std::vector<int32_t>& lcol, const std::vector<int32_t>& lrp, const double* vsrc,
+                         SortedLayout& L) {
+  // the largest tile whose segments fit: more rows per tile = more gathers per input line = more lanes sharing a line
+  for (int T : {kSortRows, kSortRows / 2, kSortRows / 4})
+    if (build_sorted_layout_t(s, lcol, lrp, vsrc, L, T)) return true;
+  return false;
+}
+bool build_sorted_layout_t(const CsrShard& s, const std::vector<int32_t>& lcol, const std::vector<int32_t>& lrp, const double* vsrc,
+                           SortedLayout& L, int T) {
+  if (s.es != 1 || s.nloc == 0 || s.nnz == 0) return false;
+  const int64_t ext = s.nloc + s.nhalo;
+  const int64_t K = (ext + kSortSliceElems - 1) / kSortSliceElems;
+  if (K < 2 || K > 64) return false;
+  const int64_t W = (ext + K - 1) / K;  // slices of equal width
+  const GlobalOrder order(s);
+  const int64_t ntiles = (s.nloc + T - 1) / T;
+  L.K = (int)K;
+  L.T = T;
+  L.base.assign((size_t)ntiles * (K + 1), 0);
+  L.off.assign((size_t)ntiles * K * (T + 1), 0);
+  L.col.clear(), L.val.clear(), L.pos.clear();
+  L.col.reserve((size_t)s.nnz + 4 * ntiles * K + 8);
+  L.val.reserve((size_t)s.nnz + 4 * ntiles * K + 8);
+  L.pos.reserve((size_t)s.nnz + 4 * ntiles * K + 8);
+  struct Ent {
+    int32_t col;
+    uint16_t slot;
+    double val;
+  };
+  std::vector<std::vector<Ent>> seg((size_t)K);
+  for (int64_t t = 0; t < ntiles; ++t) {
+    const int64_t r0 = t * T, r1 = std::min<int64_t>(r0 + T, s.nloc);
+    for (auto& v : seg) v.clear();
+    std::vector<int> next((size_t)K, 0);  // next free slot of every segment (row order)
+    for (int64_t r = r0; r < r1; ++r) {
+      for (int64_t k = 0; k < K; ++k) L.off[((size_t)t * K + k) * (T + 1) + (r - r0)] = (uint16_t)next[(size_t)k];
+      int prev = 0;
+      for (int64_t p = lrp[r]; p < lrp[r + 1]; ++p) {
+        const int k = (int)(order(lcol[p]) / W);
+        if (k < prev) return false;  // the row would be added out of stored order
+        prev = k;
+        if (next[(size_t)k] >= kSortCap - 4) return false;
+        seg[(size_t)k].push_back(Ent{lcol[p], (uint16_t)next[(size_t)k]++, vsrc[p]});
+      }
+    }
+    for (int64_t k = 0; k < K; ++k)
+      for (int64_t i = r1 - r0; i <= T; ++i) L.off[((size_t)t * K + k) * (T + 1) + i] = (uint16_t)next[(size_t)k];
+    for (int64_t k = 0; k < K; ++k) {
+      auto& v = seg[(size_t)k];
+      std::sort(v.begin(), v.end(), [](const Ent& a, const Ent& b) { return a.col != b.col ? a.col < b.col : a.slot < b.slot; });
+      L.base[(size_t)t * (K + 1) + k] = (int32_t)L.col.size();
+      // A lane loads 4 consecutive STORED entries with one 16-byte load and gathers them with 4 instructions; for the
+      // lanes of one gather instruction to see consecutive SORTED entries (the ones that share input lines), every full
+      // block of 256 is stored transposed: stored[4*lane + j] = sorted[64*j + lane].
+      const size_t full = v.size() / 256 * 256;
+      for (size_t b0 = 0; b0 < full; b0 += 256)
+        for (size_t q = 0; q < 256; ++q) {
+          const Ent& e = v[b0 + 64 * (q & 3) + (q >> 2)];
+          L.col.push_back(e.col), L.val.push_back(e.val), L.pos.push_back(e.slot);
+        }
+      for (size_t q = full; q < v.size(); ++q) L.col.push_back(v[q].col), L.val.push_back(v[q].val), L.pos.push_back(v[q].slot);
+      while (L.col.size() & 3) L.col.push_back(0), L.val.push_back(0.0), L.pos.push_back((uint16_t)next[(size_t)k]);  // a slot no row reads
+      if (L.col.size() > (size_t)2147483647 - 16384) return false;
+    }
+    L.base[(size_t)t * (K + 1) + K] = (int32_t)L.col.size();
+  }
+  for (int i = 0; i < 8; ++i) L.col.push_back(0), L.val.push_back(0.0), L.pos.push_back(0);  // 16-byte loads may run past the end
+  return true;
+}
+
 // The host-only half of a row shard: ranges, halo slots, local column numbering, receive segments.  No device call:
 // eigenex_plan_create exposes exactly this to hosts without a GPU (the gloo tests drive it across real processes).
 int plan_shard_host(int64_t n_global, int P, int gshard, const int32_t* rowptr, const int32_t* col, int es, CsrShard& s,
@@ -508,7 +633,29 @@ int build_shard_host(eigenex_context_s* c, int64_t n_global, int gshard, const i
   const double* vsrc = val + p0 * es;
   std::vector<uint8_t> blk;
   std::vector<double> bval;
-  s.passes = choose_column_blocks(s, lcol, lrp, column_blocks, blk);
+  // Layout for scattered gathers over an input that does not fit L2: column-sorted row tiles when eligible
+  // (column_blocks -1: automatic, -2: asked for), else column-blocked passes (2..16: asked for)
+  if (column_blocks == -2 || (column_blocks == -1 && es == 1 && (s.nloc + s.nhalo) * 8 > kSliceBytes && s.nnz / std::max<int64_t>(s.nloc, 1) >= 6 &&
+                              gathers_scattered(s, lcol, lrp))) {
+    static const bool off = std::getenv("EIGENEX_NO_SORTED_TILES") != nullptr;
+    SortedLayout L;
+    if (!(off && column_blocks == -1) && build_sorted_layout(s, lcol, lrp, vsrc, L)) {
+      s.sorted = true;
+      s.nslices = L.K;
+      s.tile_rows = L.T;
+      CHK(upload_vec(c, &s.s_base, L.base, 8));
+      CHK(upload_vec(c, &s.col, L.col, 8));
+      CHK(upload_vec(c, &s.val, L.val, 8));
+      CHK(upload_vec(c, &s.s_pos, L.pos, 8));
+      CHK(upload_vec(c, &s.s_off, L.off, 8));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      return 0;
+    }
+    if (column_blocks == -2)
+      return fail(EIGENEX_ERR_ARG, "column-sorted row tiles need a real operator whose rows meet the 256 KB input slices in stored order, "
+                                   "2..64 slices and fewer than 8188 entries per (1024-row tile, slice)");
+  }
+  s.passes = choose_column_blocks(s, lcol, lrp, column_blocks == -2 ? -1 : column_blocks, blk);
   if (s.passes > 1) {
     // stable counting sort of the entries by (pass, row): pass k's entries are contiguous, rows keep stored order
     const int K = s.passes;
@@ -556,13 +703,6 @@ int build_shard_host(eigenex_context_s* c, int64_t n_global, int gshard, const i
 // `order` lists the blocks sorted by (qr, qc).  A group is the part of a sector that this shard owns (row slices are
 // copied out of the caller's blocks); a block whose columns straddle the shard's own row range is split into
 // halo-below / own / halo-above pieces, in that (global column) order.
-template <class T>
-int upload_vec(eigenex_context_s* c, T** dev, const std::vector<T>& host, size_t extra = 0) {
-  HIPCHK(hipMalloc(dev, sizeof(T) * (host.size() + extra + 1)));
-  HIPCHK(hipMemsetAsync(*dev, 0, sizeof(T) * (host.size() + extra + 1), c->stream));
-  if (!host.empty()) HIPCHK(hipMemcpyAsync(*dev, host.data(), sizeof(T) * host.size(), hipMemcpyHostToDevice, c->stream));
-  return 0;
-}
 
 int build_block_shard_host(eigenex_context_s* c, int64_t n_global, int gshard, const std::vector<int64_t>& ro,
                            const std::vector<int64_t>& co, const std::vector<int>& order, const int64_t* qr,
@@ -935,6 +1075,11 @@ int enq_orthogonalize(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_t
 void launch_operator(hipStream_t st, const CsrShard* m, int es, const double* x_ext, const double* scale, double shift,
                      double shift_im, double* y, double* u_out, double* partials, int pstride, int grid, const Ctrl* ctrl,
                      int flags, int last_pass_flags = 0) {
+  if (m->sorted) {
+    const SortedOperatorView op{m->s_base, m->col, m->val, m->s_pos, m->s_off, m->nslices, m->tile_rows};
+    launch_spmv_sorted(st, op, x_ext, scale, shift, y, u_out, m->nloc, partials, ctrl, last_pass_flags);
+    return;
+  }
   if (m->blocked) {
     const BlockOperatorView op{m->bval, m->gent, m->gcol, m->cols, m->grow0, m->rowgrp};
     if (es == 2)
@@ -1671,7 +1816,7 @@ int eigenex_profile_get(eigenex_context_t c, int kind, int64_t* launches, double
 // ---- operator ---------------------------------------------------------------
 static int csr_upload_impl(eigenex_context_t c, int64_t n_global, int64_t row_begin, int64_t n_rows, const int32_t* rowptr,
                            const int32_t* col_global, const double* val, int es, int column_blocks, eigenex_csr_t* out) {
-  if (column_blocks < -1 || column_blocks > kMaxColumnBlocks) return fail(EIGENEX_ERR_ARG, "column_blocks must be in [-1, 16]");
+  if (column_blocks < -2 || column_blocks > kMaxColumnBlocks) return fail(EIGENEX_ERR_ARG, "column_blocks must be in [-2, 16]");
   if (!c || !out || !rowptr || n_global <= 0 || n_rows < 0) return fail(EIGENEX_ERR_ARG, "eigenex_csr_upload: bad argument");
   if (n_rows > 0 && rowptr[n_rows] > rowptr[0] && (!col_global || !val)) return fail(EIGENEX_ERR_ARG, "col/val is NULL");
   HIPCHK(hipSetDevice(c->device));
@@ -1872,6 +2017,17 @@ int eigenex_block_upload_z(eigenex_context_t c, int64_t n_global, int n_row_sect
   return block_upload_impl(c, n_global, n_row_sectors, row_sizes, n_col_sectors, col_sizes, nblocks, qr, qc, blocks_interleaved, 2, out);
 }
 
+int eigenex_csr_layout(eigenex_csr_t m, int* layout) {
+  if (!m || !layout) return fail(EIGENEX_ERR_ARG, "eigenex_csr_layout: NULL argument");
+  *layout = EIGENEX_LAYOUT_CSR;
+  for (auto& s : m->sh) {
+    if (s.blocked) *layout = EIGENEX_LAYOUT_DENSE_BLOCKS;
+    else if (s.sorted) *layout = EIGENEX_LAYOUT_SORTED_TILES;
+    else if (s.passes > 1 && *layout == EIGENEX_LAYOUT_CSR) *layout = EIGENEX_LAYOUT_COLUMN_BLOCKED;
+  }
+  return 0;
+}
+
 int eigenex_csr_column_blocks(eigenex_csr_t m, int* passes) {
   if (!m || !passes) return fail(EIGENEX_ERR_ARG, "eigenex_csr_column_blocks: NULL argument");
   *passes = 1;
@@ -2060,7 +2216,7 @@ int eigenex_basis_create_ex(eigenex_context_t c, eigenex_csr_t csr, int64_t n_gl
       HIPCHK(hipMalloc(&s.w, sizeof(double) * (size_t)(s.ldv + s.nhalo + 8) * s.es));
       HIPCHK(hipMemsetAsync(s.w, 0, sizeof(double) * (size_t)(s.ldv + s.nhalo + 8) * s.es, c->stream));
       s.g_vec = grid_for_tiles((s.nd + kTileRows - 1) / kTileRows, kDefaultVecBlocksPerCu);
-      s.g_spmv = grid_for_tiles((s.nloc + kSpmvRows - 1) / kSpmvRows, kDefaultSpmvBlocksPerCu);
+      s.g_spmv = (s.csr && s.csr->sorted) ? sorted_grid(s.nloc, s.csr->tile_rows) : grid_for_tiles((s.nloc + kSpmvRows - 1) / kSpmvRows, kDefaultSpmvBlocksPerCu);
       // room for eigenex_basis_tune up to kMaxBlocksPerCu workgroups per CU
       s.pstride = std::max(grid_for_tiles((s.nd + kTileRows - 1) / kTileRows, kMaxBlocksPerCu),
                            grid_for_tiles((s.nloc + kSpmvRows - 1) / kSpmvRows, kMaxBlocksPerCu));
@@ -2153,7 +2309,7 @@ int eigenex_basis_tune(eigenex_basis_t b, int vec_blocks_per_cu, int spmv_blocks
     return fail(EIGENEX_ERR_ARG, "eigenex_basis_tune: blocks per CU must be in [1, 16]");
   for (auto& s : b->sh) {
     s.g_vec = grid_for_tiles((s.nd + kTileRows - 1) / kTileRows, vec_blocks_per_cu);
-    s.g_spmv = grid_for_tiles((s.nloc + kSpmvRows - 1) / kSpmvRows, spmv_blocks_per_cu);
+    s.g_spmv = (s.csr && s.csr->sorted) ? sorted_grid(s.nloc, s.csr->tile_rows) : grid_for_tiles((s.nloc + kSpmvRows - 1) / kSpmvRows, spmv_blocks_per_cu);
     s.spmv_flags = flags & 3;  // bit 0: XCD-contiguous tiles, bit 1: non-temporal val/col loads
   }
   return 0;

@@ -194,7 +194,12 @@ int eigenex_csr_upload_z(eigenex_context_t ctx, int64_t n_global, int64_t row_be
  * with ascending columns); otherwise the entries of a row are added slice by slice (rounding-level difference).
  *   column_blocks = -1  automatic (what eigenex_csr_upload[_z] do): block only if the input vector exceeds L2,
  *                       rows are long enough, the gathers are scattered, and the result stays bit-identical
- *   column_blocks = 0,1 never;  2..16: that many passes, unconditionally */
+ *   column_blocks = 0,1 never;  2..16: that many passes, unconditionally
+ *   column_blocks = -2  column-sorted row tiles (what the automatic mode prefers for real operators since round 2): the
+ *                       entries of every (4096-row tile, 256 KB input slice) are stored sorted by column, so that the lanes
+ *                       of a wave gather from shared 128-byte lines, with a 16-bit slot that restores the row order for
+ *                       the sums; one launch, slices walked inside the kernel, bit-identical to the row loop.  Needs a
+ *                       real operator with 2..64 slices whose rows meet the slices in stored order; error otherwise */
 int eigenex_csr_upload_ex(eigenex_context_t ctx, int64_t n_global, int64_t row_begin, int64_t n_rows,
                           const int32_t* rowptr, const int32_t* col_global, const double* val, int is_complex,
                           int column_blocks, eigenex_csr_t* out);
@@ -221,6 +226,9 @@ int eigenex_csr_upload_device(eigenex_context_t ctx, int64_t n, const int32_t* r
                               const double* val_dev, int is_complex, eigenex_csr_t* out);
 /* passes of the (largest) local shard: 1 = not column-blocked */
 int eigenex_csr_column_blocks(eigenex_csr_t csr, int* passes);
+/* how the operator is stored on the device (the layout never changes a result when it was chosen automatically) */
+enum { EIGENEX_LAYOUT_CSR = 0, EIGENEX_LAYOUT_COLUMN_BLOCKED = 1, EIGENEX_LAYOUT_SORTED_TILES = 2, EIGENEX_LAYOUT_DENSE_BLOCKS = 3 };
+int eigenex_csr_layout(eigenex_csr_t csr, int* layout);
 /* synthetic 7-point Laplacian on an n^3 grid generated on the device (BASELINE configs 2 and 4) */
 int eigenex_csr_laplacian3d(eigenex_context_t ctx, int64_t n, eigenex_csr_t* out);
 int eigenex_csr_destroy(eigenex_csr_t csr);

@@ -694,3 +694,58 @@ def test_arnoldi_orthogonality_when_ritz_values_converge(capi, shards):
         b.close()
     np.testing.assert_array_equal(Hs[0], Hs[1])
     ctx.close()
+
+
+@pytest.mark.parametrize("shards", [1, 3])
+def test_column_sorted_row_tiles_bit_exact(capi, shards):
+    """k_spmv_sorted (column-sorted row tiles, the layout for scattered gathers over an input larger than L2): stored
+    order of the sums is kept through the 16-bit slots, so the result is the oracle's row loop bit for bit -- ragged
+    rows (empty ones, rows of 1..60 entries), a tile boundary inside the matrix, a last partial tile, 2 and 5 input
+    slices, shift, the fused alpha dot, and a Lanczos run equal to the plain CSR layout's."""
+    rng = np.random.default_rng(31)
+    # (rows, longest ordinary row): 200,000 rows x ~8 entries over 7 input slices fit the full 4096-row tiles (4 rows per
+    # thread), x ~20 entries 2048-row tiles, 70,001 rows x ~20 over 3 slices only 1024-row tiles
+    for n, top in ((200_000, 17), (200_000, 41), (70_001, 41)):
+        counts = rng.integers(0, top, n)
+        counts[rng.integers(0, n, n // 50)] = 0
+        counts[rng.integers(0, n, 20)] = 60
+        rowptr = np.zeros(n + 1, np.int64)
+        np.cumsum(counts, out=rowptr[1:])
+        nnz = int(rowptr[-1])
+        col = rng.integers(0, n, nnz).astype(np.int64)
+        # ascending columns within every row (duplicates allowed: they are separate stored entries)
+        order = np.lexsort((col, np.repeat(np.arange(n), counts)))
+        col = col[order].astype(np.int32)
+        val = rng.uniform(-1, 1, nnz)
+        x = rng.standard_normal(n)
+        y_ref = cref.csr_spmv(rowptr.astype(np.int32), col, val, x, nthreads=4)
+        ctx = capi.Context(loopback_shards=shards) if shards > 1 else capi.Context()
+        A = capi.Csr.upload(ctx, n, rowptr.astype(np.int32), col, val, column_blocks=-2)
+        assert A.layout() == "sorted_tiles"
+        b = capi.Basis(ctx, A, n, 2)
+        b.upload(capi.VEC_W, x)
+        dot = b.apply(capi.VEC_W, capi.VEC_V, 0.0, want_dot=True)
+        np.testing.assert_array_equal(b.download(capi.VEC_V), y_ref)
+        assert abs(dot - x @ y_ref) <= 1e-12 * np.linalg.norm(x) * np.linalg.norm(y_ref)
+        b.apply(capi.VEC_W, capi.VEC_V, 0.75)
+        np.testing.assert_array_equal(b.download(capi.VEC_V), y_ref + 0.75 * x)  # the oracle adds shift*x unfused too
+        b.close()
+        # a Krylov run: identical coefficients with the plain layout (symmetrised pattern not needed for equality)
+        res = []
+        for K in (-2, 0):
+            A2 = capi.Csr.upload(ctx, n, rowptr.astype(np.int32), col, val, column_blocks=K)
+            b2 = capi.Basis(ctx, A2, n, 9)
+            b2.upload(capi.VEC_W, x)
+            b2.arnoldi_enqueue(9)
+            st, H = b2.arnoldi_state()
+            res.append(H.copy())
+            b2.close()
+            A2.close()
+        np.testing.assert_array_equal(res[0], res[1])
+        A.close()
+        ctx.close()
+    # not eligible: one input slice only
+    ctx = capi.Context()
+    with pytest.raises(capi.EigenexError, match="column-sorted row tiles"):
+        capi.Csr.upload(ctx, 1000, np.arange(1001, dtype=np.int32), np.arange(1000, dtype=np.int32), np.ones(1000), column_blocks=-2)
+    ctx.close()
