@@ -45,6 +45,14 @@ def load_counter(d: str, counter: str):
 
 def main():
     rnd, key, stats_dir, fetch_dir, write_dir = sys.argv[1:6]
+    import subprocess
+    try:
+        head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+        dirty = bool(subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "cmpt-eigenex_amd/csrc", "bench.py"], text=True).strip())
+    except Exception:
+        head, dirty = "unknown", False
+    source = f"commit {head}{' + uncommitted changes' if dirty else ''}: kernels and bench.py as profiled"
+
     out_dir = os.path.join(ROOT, "profiles")
     os.makedirs(out_dir, exist_ok=True)
     stats_file = glob.glob(os.path.join(stats_dir, "**", "*_kernel_stats.csv"), recursive=True)[0]
@@ -63,7 +71,7 @@ def main():
     fetch = load_counter(fetch_dir, "FETCH_SIZE")
     write = load_counter(write_dir, "WRITE_SIZE")
     traffic = {}
-    lines = [f"# rocprofv3 summary, round {rnd}: {key}", "",
+    lines = [f"# rocprofv3 summary, round {rnd}: {key}", "", f"Source: {source}.", "",
              "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline`",
              "PMC: separate passes `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` over `bench.py --steps 1 --warmup 0`; "
              "HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 correction of MI355X_MICROARCH.md).", "",
@@ -82,6 +90,7 @@ def main():
     open(os.path.join(out_dir, f"{rnd}_summary.md"), "w").write("\n".join(lines) + "\n")
     tfile = os.path.join(out_dir, "hbm_traffic.json")
     allt = json.load(open(tfile)) if os.path.exists(tfile) else {}
+    traffic["__source__"] = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, {source}"
     allt[key] = traffic
     json.dump(allt, open(tfile, "w"), indent=1, sort_keys=True)
     print("\n".join(lines))
