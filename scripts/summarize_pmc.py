@@ -34,7 +34,8 @@ def short(name: str) -> str:
 def load_counters(d):
     """{kernel: {counter: [value per dispatch]}}; values of one dispatch are summed over dimensions"""
     per = defaultdict(lambda: defaultdict(dict))
-    for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+    files = sorted(glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:  # gpurun merges into existing directories: only the newest run of a pass counts
         for row in csv.DictReader(open(f)):
             k = short(row["Kernel_Name"])
             disp = row.get("Dispatch_Id") or row.get("Correlation_Id")
@@ -50,7 +51,7 @@ def main():
     title = args[args.index("--title") + 1] if "--title" in args else name
     only = args[args.index("--kernels") + 1].split(",") if "--kernels" in args else None
     base = os.path.join(ROOT, "gpurun_out")
-    stats_files = glob.glob(os.path.join(base, f"prof_{name}_stats", "**", "*_kernel_stats.csv"), recursive=True)
+    stats_files = sorted(glob.glob(os.path.join(base, f"prof_{name}_stats", "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)[-1:]
     stats = {}
     if stats_files:
         for r in csv.DictReader(open(stats_files[0])):
@@ -76,6 +77,7 @@ def main():
         head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
     except Exception:
         head = "unknown"
+    head = os.environ.get("PROFILED_COMMIT", head)
     lines = [f"# {title}", "",
              f"Source tree: commit `{head}` (+ working tree at the time of the run). rocprofv3 passes, each its own run: "
              f"`--kernel-trace --stats`" + "".join(f"; `--pmc {' '.join(n)}`" for _, n in groups) + ".",

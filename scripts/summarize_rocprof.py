@@ -36,7 +36,8 @@ def short(name: str) -> str:
 
 def load_counter(d: str, counter: str):
     per = defaultdict(list)
-    for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+    files = sorted(glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:  # gpurun merges into existing directories: only the newest run of a pass counts
         for row in csv.DictReader(open(f)):
             if row["Counter_Name"] == counter:
                 per[short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
@@ -51,11 +52,13 @@ def main():
         dirty = bool(subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "cmpt-eigenex_amd/csrc", "bench.py"], text=True).strip())
     except Exception:
         head, dirty = "unknown", False
+    if os.environ.get("PROFILED_COMMIT"):  # the summary is written after the run: name the commit that was on the GPU box
+        head, dirty = os.environ["PROFILED_COMMIT"], False
     source = f"commit {head}{' + uncommitted changes' if dirty else ''}: kernels and bench.py as profiled"
 
     out_dir = os.path.join(ROOT, "profiles")
     os.makedirs(out_dir, exist_ok=True)
-    stats_file = glob.glob(os.path.join(stats_dir, "**", "*_kernel_stats.csv"), recursive=True)[0]
+    stats_file = sorted(glob.glob(os.path.join(stats_dir, "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)[-1]
     shutil.copy(stats_file, os.path.join(out_dir, f"{rnd}_kernel_stats.csv"))
     stats = {}
     for r in csv.DictReader(open(stats_file)):
