@@ -76,7 +76,7 @@ def main():
     traffic = {}
     lines = [f"# rocprofv3 summary, round {rnd}: {key}", "", f"Source: {source}.", "",
              "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline`",
-             "PMC: separate passes `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` over `bench.py --steps 1 --warmup 0`; "
+             "PMC: separate passes `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` over the same command; "
              "HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 correction of MI355X_MICROARCH.md).", "",
              "| kernel | calls | avg ms | % time | HBM bytes/launch (PMC) | fetch KiB avg (raw) | write KiB avg |", "|---|---|---|---|---|---|---|"]
     for k, r in sorted(stats.items(), key=lambda kv: -float(kv[1]["TotalDurationNs"])):
