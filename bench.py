@@ -232,6 +232,12 @@ def main():
         sys.exit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch with --nproc-per-node {args.gpus}, or call "
                  f"bench.py without a launcher and let it start its own ranks")
 
+    # stdout carries exactly one line, the JSON result: libraries that print there (RCCL prints a version banner to
+    # stdout when a communicator is created) are sent to stderr for the whole run; the line goes to the saved descriptor
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -422,7 +428,8 @@ def main():
                     np.abs(np.asarray(r["alpha"][:k]) - same_input["alpha"]).max(),
                     np.abs(np.asarray(r["beta"][:k - 1]) - same_input["beta"][:k - 1]).max()))
             out["cpu_baseline"] = cb
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
 
     es.close()
     A.close()
