@@ -1,0 +1,147 @@
+"""RCCL between real ranks (one process per GPU).  Skipped on a one-GPU box (RCCL refuses two ranks on one device); on a
+node with >= 2 GPUs it is the test that the loopback transport stands in for everywhere else: the same sharded Lanczos /
+Arnoldi runs, rank by rank over RCCL, must reproduce the in-process loopback run of the same partition BIT FOR BIT
+(same kernels, same partial sums; ncclAllReduce of 2 ranks adds the same two numbers as k_sum_shards) -- for the
+device-generated stencil (closed-form halo plan), for an uploaded random sparse matrix (request lists exchanged over RCCL,
+pack kernel) and with the alpha fusion on and off; Ritz vectors come back as the rank's rows.  (ADVICE r1, low.)"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _matrices(n_lap, n_rand):
+    sys.path.insert(0, ROOT)
+    import scipy.sparse as sp
+
+    from oracle import cref
+
+    lap = cref.laplacian3d(n_lap)
+    A = sp.random(n_rand, n_rand, density=7.0 / n_rand, random_state=9, format="csr")
+    A = (A + A.T + sp.diags(np.linspace(1.0, 3.0, n_rand))).tocsr()
+    A.sort_indices()
+    return lap, (A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64))
+
+
+def _runs(capi, ctx, world, rank, n_lap, n_rand, m):
+    """alpha/beta (Lanczos) and H (Arnoldi) of every case on this context; rank = None: all shards (loopback)"""
+    lap, rnd = _matrices(n_lap, n_rand)
+    out = {}
+    for name, (rowptr, col, val), N in (("lap_upload", lap, n_lap ** 3), ("rand", rnd, n_rand)):
+        if rank is None:
+            A = capi.Csr.upload(ctx, N, rowptr, col, val)
+        else:
+            rb, re = capi.partition(N, world, rank)
+            A = capi.Csr.upload(ctx, N, rowptr[rb:re + 1] - rowptr[rb], col[rowptr[rb]:rowptr[re]], val[rowptr[rb]:rowptr[re]], row_begin=rb)
+        init = np.random.default_rng(3).standard_normal(N)
+        sl = slice(None) if rank is None else slice(*capi.partition(N, world, rank))
+        for fused in (True, False):
+            b = capi.Basis(ctx, A, N, m + 1)
+            b.set_alpha_fusion(fused)
+            b.upload(capi.VEC_W, init[sl])
+            b.lanczos_enqueue(m + 1)
+            st, al, be = b.lanczos_state()
+            assert st.nvec == m + 1
+            out[f"{name}_lanczos_{int(fused)}"] = np.concatenate([al, be])
+            b.close()
+        b = capi.Basis(ctx, A, N, m)
+        b.configure(ortho_mode=capi.ORTHO_BATCHED_ADAPTIVE)
+        b.upload(capi.VEC_W, init[sl])
+        b.arnoldi_enqueue(m)
+        out[f"{name}_arnoldi"] = b.arnoldi_state()[1].ravel()
+        b.close()
+        A.close()
+    A = capi.Csr.laplacian3d(ctx, n_lap)
+    N = n_lap ** 3
+    sl = slice(None) if rank is None else slice(*capi.partition(N, world, rank))
+    b = capi.Basis(ctx, A, N, m + 1)
+    b.upload(capi.VEC_W, np.random.default_rng(3).standard_normal(N)[sl])
+    b.lanczos_enqueue(m + 1)
+    st, al, be = b.lanczos_state()
+    out["lap_generated_lanczos"] = np.concatenate([al, be])
+    b.close()
+    A.close()
+    return out
+
+
+def _worker(rank, world, port, n_lap, n_rand, m, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from cmpt_eigenex_amd import capi
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    ids = [capi.rccl_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(ids, src=0)
+    ctx = capi.Context(device=rank, rank=rank, world_size=world, rccl_id=ids[0])
+    assert ctx.rccl_selftest()
+    assert ctx.comm_info()[0] == world
+    res = _runs(capi, ctx, world, rank, n_lap, n_rand, m)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
+    ctx.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rccl_ranks_reproduce_the_loopback_run_bit_for_bit(world, tmp_path):
+    import multiprocessing as mp
+
+    from cmpt_eigenex_amd import capi
+
+    if capi.device_count() < world:
+        pytest.skip(f"needs {world} GPUs (this box has {capi.device_count()}): RCCL refuses two ranks on one device")
+    n_lap, n_rand, m = 14, 3001, 18
+    lctx = capi.Context(loopback_shards=world)
+    want = _runs(capi, lctx, world, None, n_lap, n_rand, m)
+    lctx.close()
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_lap, n_rand, m, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+        assert p.exitcode == 0
+    for r in range(world):
+        got = np.load(tmp_path / f"rank{r}.npz")
+        for key, v in want.items():
+            if world == 2:  # a + b is the same number in either order
+                np.testing.assert_array_equal(got[key], v, err_msg=f"rank {r} {key}")
+            else:  # three addends: RCCL's reduction order is its own
+                np.testing.assert_allclose(got[key], v, rtol=0, atol=1e-11, err_msg=f"rank {r} {key}")
+            if r:
+                np.testing.assert_array_equal(got[key], np.load(tmp_path / "rank0.npz")[key])  # ranks agree bit for bit
+
+
+def test_one_rank_communicator_runs_the_same_cases():
+    """What a one-GPU box can run of the above: the per-rank code path (row slices, uploads with row_begin, all-reduces and
+    the alpha fusion through ncclAllReduce) on a 1-rank communicator against a plain single-GPU context."""
+    from cmpt_eigenex_amd import capi
+
+    n_lap, n_rand, m = 14, 3001, 18
+    plain = capi.Context()
+    want = _runs(capi, plain, 1, None, n_lap, n_rand, m)
+    plain.close()
+    ctx = capi.Context(rank=0, world_size=1, rccl_id=capi.rccl_unique_id())
+    got = _runs(capi, ctx, 1, 0, n_lap, n_rand, m)
+    ctx.close()
+    for key, v in want.items():
+        np.testing.assert_allclose(got[key], v, rtol=0, atol=1e-11, err_msg=key)
