@@ -544,7 +544,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int32_t* __restrict__ row
 //     L2-resident; all workgroups are in the same slice at about the same time) INSIDE the kernel, row sums in
 //     registers: no carry through memory between slices;
 //   * the entries of one (tile, slice) -- ~4096 on config 3, 2 per input line -- are STORED sorted by column
-//     (col, val, and a 16-bit slot = position of the entry in row order), so consecutive lanes gather from the same
+//     (8-byte value + 4 bytes holding the column's position in the slice and a 16-bit slot = place of the entry in row
+//     order: 12 bytes per entry like plain CSR), so consecutive lanes gather from the same
 //     or neighbouring lines; products are scattered into LDS by slot (index skewed like above);
 //   * row phase: every thread adds the products of its 4 rows in stored order, slice after slice = the stored
 //     order of the row when its columns ascend: still bit-identical to the oracle's row loop.
@@ -564,9 +565,8 @@ __device__ __forceinline__ double block_sum16(double x, double* lds16) {
 
 // entries of one segment held in registers between the loads and their use: two rounds of 4 per lane (<= 8192 entries)
 struct SortedRegs {
-  int4 ca, cb;
+  uint4 ca, cb;  // packed (column position in the slice | slot << 16)
   double2 a01, a23, b01, b23;
-  ushort4 pa, pb;
   bool in0, in1;
 };
 struct SortedX {
@@ -576,35 +576,44 @@ __device__ __forceinline__ void sorted_load(SortedRegs& g, const SortedOperatorV
   const int q0 = e0 + 4 * tid, q1 = q0 + 4 * kSortBlock;
   g.in0 = q0 < e1, g.in1 = q1 < e1;
   if (g.in0) {
-    g.ca = *reinterpret_cast<const int4*>(op.col + q0);
+    g.ca = *reinterpret_cast<const uint4*>(op.cp + q0);
     g.a01 = ld2(op.val + q0);
     g.a23 = ld2(op.val + q0 + 2);
-    g.pa = *reinterpret_cast<const ushort4*>(op.pos + q0);
   }
   if (g.in1) {
-    g.cb = *reinterpret_cast<const int4*>(op.col + q1);
+    g.cb = *reinterpret_cast<const uint4*>(op.cp + q1);
     g.b01 = ld2(op.val + q1);
     g.b23 = ld2(op.val + q1 + 2);
-    g.pb = *reinterpret_cast<const ushort4*>(op.pos + q1);
   }
 }
-__device__ __forceinline__ void sorted_gather(SortedX& x, const SortedRegs& g, const double* __restrict__ x_ext) {
+// index into the operator input of the column at position `c & 0xffff` of slice k
+__device__ __forceinline__ int64_t sorted_index(const SortedOperatorView& op, int64_t slice_pos0, unsigned c) {
+  const int64_t p = slice_pos0 + (c & 0xffffu);
+  return p < op.n_low ? op.npad + p : (p < op.n_low + op.nloc ? p - op.n_low : op.npad + p - op.nloc);
+}
+__device__ __forceinline__ void sorted_gather(SortedX& x, const SortedRegs& g, const SortedOperatorView& op, int k,
+                                              const double* __restrict__ x_ext) {
+  const int64_t p0 = (int64_t)k * op.slice_width;
   x.a0 = x.a1 = x.a2 = x.a3 = x.b0 = x.b1 = x.b2 = x.b3 = 0.0;
-  if (g.in0) x.a0 = x_ext[g.ca.x], x.a1 = x_ext[g.ca.y], x.a2 = x_ext[g.ca.z], x.a3 = x_ext[g.ca.w];  // all eight in flight
-  if (g.in1) x.b0 = x_ext[g.cb.x], x.b1 = x_ext[g.cb.y], x.b2 = x_ext[g.cb.z], x.b3 = x_ext[g.cb.w];
+  if (g.in0)  // all eight in flight
+    x.a0 = x_ext[sorted_index(op, p0, g.ca.x)], x.a1 = x_ext[sorted_index(op, p0, g.ca.y)], x.a2 = x_ext[sorted_index(op, p0, g.ca.z)],
+    x.a3 = x_ext[sorted_index(op, p0, g.ca.w)];
+  if (g.in1)
+    x.b0 = x_ext[sorted_index(op, p0, g.cb.x)], x.b1 = x_ext[sorted_index(op, p0, g.cb.y)], x.b2 = x_ext[sorted_index(op, p0, g.cb.z)],
+    x.b3 = x_ext[sorted_index(op, p0, g.cb.w)];
 }
 __device__ __forceinline__ void sorted_scatter(const SortedRegs& g, const SortedX& x, double scale, double* prod) {
   if (g.in0) {
-    prod[skew(g.pa.x)] = g.a01.x * (x.a0 * scale);
-    prod[skew(g.pa.y)] = g.a01.y * (x.a1 * scale);
-    prod[skew(g.pa.z)] = g.a23.x * (x.a2 * scale);
-    prod[skew(g.pa.w)] = g.a23.y * (x.a3 * scale);
+    prod[skew(g.ca.x >> 16)] = g.a01.x * (x.a0 * scale);
+    prod[skew(g.ca.y >> 16)] = g.a01.y * (x.a1 * scale);
+    prod[skew(g.ca.z >> 16)] = g.a23.x * (x.a2 * scale);
+    prod[skew(g.ca.w >> 16)] = g.a23.y * (x.a3 * scale);
   }
   if (g.in1) {
-    prod[skew(g.pb.x)] = g.b01.x * (x.b0 * scale);
-    prod[skew(g.pb.y)] = g.b01.y * (x.b1 * scale);
-    prod[skew(g.pb.z)] = g.b23.x * (x.b2 * scale);
-    prod[skew(g.pb.w)] = g.b23.y * (x.b3 * scale);
+    prod[skew(g.cb.x >> 16)] = g.b01.x * (x.b0 * scale);
+    prod[skew(g.cb.y >> 16)] = g.b01.y * (x.b1 * scale);
+    prod[skew(g.cb.z >> 16)] = g.b23.x * (x.b2 * scale);
+    prod[skew(g.cb.w >> 16)] = g.b23.y * (x.b3 * scale);
   }
 }
 
@@ -643,7 +652,7 @@ __global__ __launch_bounds__(kSortBlock) void k_spmv_sorted(SortedOperatorView o
     };
     sorted_load(g, op, tb[0], tb[1], tid);
     load_offsets(o, 0);
-    sorted_gather(x, g, x_ext);
+    sorted_gather(x, g, op, 0, x_ext);
     for (int k = 0; k < K; ++k) {
       double* prod = lds_prod + (k & 1) * kSortBufDoubles;
       if (k + 1 < K) {  // (a) entry streams and offsets of the next segment
@@ -652,7 +661,7 @@ __global__ __launch_bounds__(kSortBlock) void k_spmv_sorted(SortedOperatorView o
       }
       sorted_scatter(g, x, scale, prod);  // (b) products of segment k (waits for its gathers)
       __syncthreads();                    // (c) the only barrier: buffer k&1 complete; buffer (k+1)&1 free since the last one
-      if (k + 1 < K) sorted_gather(x, gn, x_ext);  // (d) gathers of segment k+1 fly during the row phase
+      if (k + 1 < K) sorted_gather(x, gn, op, k + 1, x_ext);  // (d) gathers of segment k+1 fly during the row phase
       // (e) row phase: stored order within the slice, multiply-then-add.  (Reading a thread's first 8 slots with
       // independent LDS loads and handing them to the rows by compares was measured slower: 184 vs 171 us.)
 #pragma unroll

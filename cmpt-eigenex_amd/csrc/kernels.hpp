@@ -75,7 +75,7 @@ void launch_spmv(hipStream_t s, const int32_t* rowptr, const int32_t* col, const
                  const Ctrl* ctrl, int spmv_flags = 0, int pass = 0);
 // Column-sorted row tiles (real fp64; kernels.hip: k_spmv_sorted): tile t = rows [t*T, (t+1)*T), T = tile_rows, slice k =
 // the k-th range of the operator input (global column order).  Segment (t, k) = entries base[t*(K+1)+k] .. base[t*(K+1)+k+1)
-// of col/val/pos, sorted by column, padded to a multiple of 4 (val 0, a spare slot); pos = slot of the entry in row order
+// of cp/val, sorted by column, padded to a multiple of 4 (val 0, a spare slot); slot = place of the entry in row order
 // inside the segment; off[(t*K+k)*(T+1) + i] = first slot of row i of the tile (so a row's products are added
 // in stored order).  At most kSortCap - 4 entries per segment.
 constexpr int kSortRows = 4096;
@@ -85,12 +85,14 @@ constexpr int kSortBufDoubles = kSortCap + kSortCap / 32 + 8;
 constexpr int kSortSliceElems = 32768;    // <= 256 KB of fp64 input per slice
 struct SortedOperatorView {
   const int32_t* base;
-  const int32_t* col;
+  const uint32_t* cp;   // per entry: column position inside its slice (low 16 bits) | row-order slot (high 16 bits)
   const double* val;
-  const uint16_t* pos;
   const uint16_t* off;
   int nslices;
-  int tile_rows;  // 4096, 2048 or 1024: the largest for which every segment fits the product buffer
+  int tile_rows;        // 4096, 2048 or 1024: the largest for which every segment fits the product buffer
+  int slice_width;      // positions per slice (<= 32768); position = place of a column in GLOBAL column order
+  int64_t n_low, npad, nloc;  // position p -> index into the operator input: p < n_low: halo slot p (at npad + p);
+                              // p < n_low + nloc: own row p - n_low; else halo slot p - nloc (at npad + p - nloc)
 };
 int sorted_grid(int64_t n, int tile_rows);
 void launch_spmv_sorted(hipStream_t s, const SortedOperatorView& op, const double* x_ext, const double* scale, double shift, double* y,

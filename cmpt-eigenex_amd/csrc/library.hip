@@ -199,7 +199,10 @@ struct CsrShard {
   bool sorted = false;
   int nslices = 0, tile_rows = 0;
   int32_t* s_base = nullptr;
-  uint16_t *s_pos = nullptr, *s_off = nullptr;
+  uint32_t* s_cp = nullptr;
+  uint16_t* s_off = nullptr;
+  int s_width = 0;
+  int64_t s_nlow = 0;
   // block-sparse format (eigenex_block_upload; kernels.hpp: BlockOperatorView) instead of rowptr/col/val
   bool blocked = false;
   double* bval = nullptr;
@@ -365,7 +368,7 @@ void free_csr_shard(CsrShard& s) {
   if (s.send_idx) (void)hipFree(s.send_idx);
   if (s.sendbuf) (void)hipFree(s.sendbuf);
   for (void* p : {(void*)s.bval, (void*)s.gent, (void*)s.gcol, (void*)s.cols, (void*)s.grow0, (void*)s.rowgrp, (void*)s.s_base,
-                  (void*)s.s_pos, (void*)s.s_off})
+                  (void*)s.s_cp, (void*)s.s_off})
     if (p) (void)hipFree(p);
   s = CsrShard();
 }
@@ -510,10 +513,12 @@ bool gathers_scattered(const CsrShard& s, const std::vector<int32_t>& lcol, cons
 // stored order (so the result stays bit-identical to the row loop), a (tile, slice) segment fits the LDS product buffer
 // and the slice count stays small.  Returns false (nothing built) otherwise.
 struct SortedLayout {
-  int K = 0, T = 0;
-  std::vector<int32_t> base, col;
+  int K = 0, T = 0, W = 0;
+  int64_t n_low = 0;
+  std::vector<int32_t> base;
+  std::vector<uint32_t> cp;
   std::vector<double> val;
-  std::vector<uint16_t> pos, off;
+  std::vector<uint16_t> off;
 };
 bool build_sorted_layout_t(const CsrShard& s, const std::vector<int32_t>& lcol, const std::vector<int32_t>& lrp, const double* vsrc,
                            SortedLayout& L, int T);
@@ -537,12 +542,13 @@ bool build_sorted_layout_t(const CsrShard& s, const std::vector<int32_t>& lcol, 
   L.T = T;
   L.base.assign((size_t)ntiles * (K + 1), 0);
   L.off.assign((size_t)ntiles * K * (T + 1), 0);
-  L.col.clear(), L.val.clear(), L.pos.clear();
-  L.col.reserve((size_t)s.nnz + 4 * ntiles * K + 8);
+  L.W = (int)W;
+  L.n_low = order.n_low;
+  L.cp.clear(), L.val.clear();
+  L.cp.reserve((size_t)s.nnz + 4 * ntiles * K + 8);
   L.val.reserve((size_t)s.nnz + 4 * ntiles * K + 8);
-  L.pos.reserve((size_t)s.nnz + 4 * ntiles * K + 8);
   struct Ent {
-    int32_t col;
+    uint16_t col;  // position of the column inside its slice
     uint16_t slot;
     double val;
   };
@@ -555,11 +561,12 @@ bool build_sorted_layout_t(const CsrShard& s, const std::vector<int32_t>& lcol, 
       for (int64_t k = 0; k < K; ++k) L.off[((size_t)t * K + k) * (T + 1) + (r - r0)] = (uint16_t)next[(size_t)k];
       int prev = 0;
       for (int64_t p = lrp[r]; p < lrp[r + 1]; ++p) {
-        const int k = (int)(order(lcol[p]) / W);
+        const int64_t pos = order(lcol[p]);
+        const int k = (int)(pos / W);
         if (k < prev) return false;  // the row would be added out of stored order
         prev = k;
         if (next[(size_t)k] >= kSortCap - 4) return false;
-        seg[(size_t)k].push_back(Ent{lcol[p], (uint16_t)next[(size_t)k]++, vsrc[p]});
+        seg[(size_t)k].push_back(Ent{(uint16_t)(pos - (int64_t)k * W), (uint16_t)next[(size_t)k]++, vsrc[p]});
       }
     }
     for (int64_t k = 0; k < K; ++k)
@@ -567,7 +574,7 @@ bool build_sorted_layout_t(const CsrShard& s, const std::vector<int32_t>& lcol, 
     for (int64_t k = 0; k < K; ++k) {
       auto& v = seg[(size_t)k];
       std::sort(v.begin(), v.end(), [](const Ent& a, const Ent& b) { return a.col != b.col ? a.col < b.col : a.slot < b.slot; });
-      L.base[(size_t)t * (K + 1) + k] = (int32_t)L.col.size();
+      L.base[(size_t)t * (K + 1) + k] = (int32_t)L.cp.size();
       // A lane loads 4 consecutive STORED entries with one 16-byte load and gathers them with 4 instructions; for the
       // lanes of one gather instruction to see consecutive SORTED entries (the ones that share input lines), every full
       // block of 256 is stored transposed: stored[4*lane + j] = sorted[64*j + lane].
@@ -575,15 +582,15 @@ bool build_sorted_layout_t(const CsrShard& s, const std::vector<int32_t>& lcol, 
       for (size_t b0 = 0; b0 < full; b0 += 256)
         for (size_t q = 0; q < 256; ++q) {
           const Ent& e = v[b0 + 64 * (q & 3) + (q >> 2)];
-          L.col.push_back(e.col), L.val.push_back(e.val), L.pos.push_back(e.slot);
+          L.cp.push_back((uint32_t)e.col | ((uint32_t)e.slot << 16)), L.val.push_back(e.val);
         }
-      for (size_t q = full; q < v.size(); ++q) L.col.push_back(v[q].col), L.val.push_back(v[q].val), L.pos.push_back(v[q].slot);
-      while (L.col.size() & 3) L.col.push_back(0), L.val.push_back(0.0), L.pos.push_back((uint16_t)next[(size_t)k]);  // a slot no row reads
-      if (L.col.size() > (size_t)2147483647 - 16384) return false;
+      for (size_t q = full; q < v.size(); ++q) L.cp.push_back((uint32_t)v[q].col | ((uint32_t)v[q].slot << 16)), L.val.push_back(v[q].val);
+      while (L.cp.size() & 3) L.cp.push_back((uint32_t)next[(size_t)k] << 16), L.val.push_back(0.0);  // column 0 of the slice, a slot no row reads
+      if (L.cp.size() > (size_t)2147483647 - 16384) return false;
     }
-    L.base[(size_t)t * (K + 1) + K] = (int32_t)L.col.size();
+    L.base[(size_t)t * (K + 1) + K] = (int32_t)L.cp.size();
   }
-  for (int i = 0; i < 8; ++i) L.col.push_back(0), L.val.push_back(0.0), L.pos.push_back(0);  // 16-byte loads may run past the end
+  for (int i = 0; i < 8; ++i) L.cp.push_back(0), L.val.push_back(0.0);  // 16-byte loads may run past the end
   return true;
 }
 
@@ -644,9 +651,10 @@ int build_shard_host(eigenex_context_s* c, int64_t n_global, int gshard, const i
       s.nslices = L.K;
       s.tile_rows = L.T;
       CHK(upload_vec(c, &s.s_base, L.base, 8));
-      CHK(upload_vec(c, &s.col, L.col, 8));
+      s.s_width = L.W;
+      s.s_nlow = L.n_low;
+      CHK(upload_vec(c, &s.s_cp, L.cp, 8));
       CHK(upload_vec(c, &s.val, L.val, 8));
-      CHK(upload_vec(c, &s.s_pos, L.pos, 8));
       CHK(upload_vec(c, &s.s_off, L.off, 8));
       HIPCHK(hipStreamSynchronize(c->stream));
       return 0;
@@ -1076,7 +1084,7 @@ void launch_operator(hipStream_t st, const CsrShard* m, int es, const double* x_
                      double shift_im, double* y, double* u_out, double* partials, int pstride, int grid, const Ctrl* ctrl,
                      int flags, int last_pass_flags = 0) {
   if (m->sorted) {
-    const SortedOperatorView op{m->s_base, m->col, m->val, m->s_pos, m->s_off, m->nslices, m->tile_rows};
+    const SortedOperatorView op{m->s_base, m->s_cp, m->val, m->s_off, m->nslices, m->tile_rows, m->s_width, m->s_nlow, m->npad, m->nloc};
     launch_spmv_sorted(st, op, x_ext, scale, shift, y, u_out, m->nloc, partials, ctrl, last_pass_flags);
     return;
   }
