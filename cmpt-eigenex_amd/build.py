@@ -50,7 +50,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     if force or _newer(so, srcs + _all_headers()):
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", so, *srcs,
                "-I", os.path.join(ROOT, "include"), "-L", os.path.join(ROCM, "lib"), "-lrccl",
-               "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-Wno-unused-value"]
+               "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-Wno-unused-value", "-pthread"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/eigenex_hip.h"
@@ -544,51 +545,99 @@ bool build_sorted_layout_t(const CsrShard& s, const std::vector<int32_t>& lcol, 
   L.off.assign((size_t)ntiles * K * (T + 1), 0);
   L.W = (int)W;
   L.n_low = order.n_low;
-  L.cp.clear(), L.val.clear();
-  L.cp.reserve((size_t)s.nnz + 4 * ntiles * K + 8);
-  L.val.reserve((size_t)s.nnz + 4 * ntiles * K + 8);
   struct Ent {
     uint16_t col;  // position of the column inside its slice
     uint16_t slot;
     double val;
   };
-  std::vector<std::vector<Ent>> seg((size_t)K);
-  for (int64_t t = 0; t < ntiles; ++t) {
-    const int64_t r0 = t * T, r1 = std::min<int64_t>(r0 + T, s.nloc);
-    for (auto& v : seg) v.clear();
-    std::vector<int> next((size_t)K, 0);  // next free slot of every segment (row order)
-    for (int64_t r = r0; r < r1; ++r) {
-      for (int64_t k = 0; k < K; ++k) L.off[((size_t)t * K + k) * (T + 1) + (r - r0)] = (uint16_t)next[(size_t)k];
-      int prev = 0;
-      for (int64_t p = lrp[r]; p < lrp[r + 1]; ++p) {
-        const int64_t pos = order(lcol[p]);
-        const int k = (int)(pos / W);
-        if (k < prev) return false;  // the row would be added out of stored order
-        prev = k;
-        if (next[(size_t)k] >= kSortCap - 4) return false;
-        seg[(size_t)k].push_back(Ent{(uint16_t)(pos - (int64_t)k * W), (uint16_t)next[(size_t)k]++, vsrc[p]});
-      }
-    }
-    for (int64_t k = 0; k < K; ++k)
-      for (int64_t i = r1 - r0; i <= T; ++i) L.off[((size_t)t * K + k) * (T + 1) + i] = (uint16_t)next[(size_t)k];
-    for (int64_t k = 0; k < K; ++k) {
-      auto& v = seg[(size_t)k];
-      std::sort(v.begin(), v.end(), [](const Ent& a, const Ent& b) { return a.col != b.col ? a.col < b.col : a.slot < b.slot; });
-      L.base[(size_t)t * (K + 1) + k] = (int32_t)L.cp.size();
-      // A lane loads 4 consecutive STORED entries with one 16-byte load and gathers them with 4 instructions; for the
-      // lanes of one gather instruction to see consecutive SORTED entries (the ones that share input lines), every full
-      // block of 256 is stored transposed: stored[4*lane + j] = sorted[64*j + lane].
-      const size_t full = v.size() / 256 * 256;
-      for (size_t b0 = 0; b0 < full; b0 += 256)
-        for (size_t q = 0; q < 256; ++q) {
-          const Ent& e = v[b0 + 64 * (q & 3) + (q >> 2)];
-          L.cp.push_back((uint32_t)e.col | ((uint32_t)e.slot << 16)), L.val.push_back(e.val);
+  // Tiles are independent: a few host threads take contiguous tile ranges (a single Arnoldi solve on config 3 takes 29 ms;
+  // the one-threaded comparison sort of 32e6 entries took 1.5 s), each building its own piece of cp/val with segment
+  // offsets relative to the piece; the pieces are joined afterwards.
+  struct Piece {
+    std::vector<uint32_t> cp;
+    std::vector<double> val;
+    bool ok = true;
+  };
+  const int nthreads = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(ntiles, 16), (int64_t)std::thread::hardware_concurrency()));
+  std::vector<Piece> pieces((size_t)nthreads);
+  auto work = [&](int th) {
+    Piece& P = pieces[(size_t)th];
+    const int64_t t0 = ntiles * th / nthreads, t1 = ntiles * (th + 1) / nthreads;
+    P.cp.reserve((size_t)((int64_t)lrp[std::min<int64_t>(t1 * T, s.nloc)] - lrp[std::min<int64_t>(t0 * T, s.nloc)]) + 4 * (size_t)(t1 - t0) * K + 8);
+    P.val.reserve(P.cp.capacity());
+    std::vector<std::vector<Ent>> seg((size_t)K);
+    std::vector<Ent> tmp;
+    std::vector<int> next((size_t)K);
+    for (int64_t t = t0; t < t1; ++t) {
+      const int64_t r0 = t * T, r1 = std::min<int64_t>(r0 + T, s.nloc);
+      for (auto& v : seg) v.clear();
+      std::fill(next.begin(), next.end(), 0);  // next free slot of every segment (row order)
+      for (int64_t r = r0; r < r1; ++r) {
+        for (int64_t k = 0; k < K; ++k) L.off[((size_t)t * K + k) * (T + 1) + (r - r0)] = (uint16_t)next[(size_t)k];
+        int prev = 0;
+        for (int64_t p = lrp[r]; p < lrp[r + 1]; ++p) {
+          const int64_t pos = order(lcol[p]);
+          const int k = (int)(pos / W);
+          if (k < prev || next[(size_t)k] >= kSortCap - 4) {  // out of stored order, or the segment does not fit the product buffer
+            P.ok = false;
+            return;
+          }
+          prev = k;
+          seg[(size_t)k].push_back(Ent{(uint16_t)(pos - (int64_t)k * W), (uint16_t)next[(size_t)k]++, vsrc[p]});
         }
-      for (size_t q = full; q < v.size(); ++q) L.cp.push_back((uint32_t)v[q].col | ((uint32_t)v[q].slot << 16)), L.val.push_back(v[q].val);
-      while (L.cp.size() & 3) L.cp.push_back((uint32_t)next[(size_t)k] << 16), L.val.push_back(0.0);  // column 0 of the slice, a slot no row reads
-      if (L.cp.size() > (size_t)2147483647 - 16384) return false;
+      }
+      for (int64_t k = 0; k < K; ++k)
+        for (int64_t i = r1 - r0; i <= T; ++i) L.off[((size_t)t * K + k) * (T + 1) + i] = (uint16_t)next[(size_t)k];
+      for (int64_t k = 0; k < K; ++k) {
+        auto& v = seg[(size_t)k];
+        // stable LSD radix sort by the 15-bit column position (two 8-bit passes); entries arrive in slot order, so equal
+        // columns stay in slot order
+        tmp.resize(v.size());
+        for (int pass = 0; pass < 2; ++pass) {
+          size_t cnt[257] = {0};
+          const int sh = 8 * pass;
+          for (const Ent& e : v) cnt[((e.col >> sh) & 255) + 1]++;
+          for (int d = 0; d < 256; ++d) cnt[d + 1] += cnt[d];
+          for (const Ent& e : v) tmp[cnt[(e.col >> sh) & 255]++] = e;
+          v.swap(tmp);
+        }
+        L.base[(size_t)t * (K + 1) + k] = (int32_t)P.cp.size();  // relative to the piece; shifted when the pieces are joined
+        // A lane loads 4 consecutive STORED entries with one 16-byte load and gathers them with 4 instructions; for the
+        // lanes of one gather instruction to see consecutive SORTED entries (the ones that share input lines), every full
+        // block of 256 is stored transposed: stored[4*lane + j] = sorted[64*j + lane].
+        const size_t full = v.size() / 256 * 256;
+        for (size_t b0 = 0; b0 < full; b0 += 256)
+          for (size_t q = 0; q < 256; ++q) {
+            const Ent& e = v[b0 + 64 * (q & 3) + (q >> 2)];
+            P.cp.push_back((uint32_t)e.col | ((uint32_t)e.slot << 16)), P.val.push_back(e.val);
+          }
+        for (size_t q = full; q < v.size(); ++q) P.cp.push_back((uint32_t)v[q].col | ((uint32_t)v[q].slot << 16)), P.val.push_back(v[q].val);
+        while (P.cp.size() & 3) P.cp.push_back((uint32_t)next[(size_t)k] << 16), P.val.push_back(0.0);  // column 0 of the slice, a slot no row reads
+      }
+      L.base[(size_t)t * (K + 1) + K] = (int32_t)P.cp.size();
     }
-    L.base[(size_t)t * (K + 1) + K] = (int32_t)L.cp.size();
+  };
+  {
+    std::vector<std::thread> pool;
+    for (int th = 1; th < nthreads; ++th) pool.emplace_back(work, th);
+    work(0);
+    for (auto& t : pool) t.join();
+  }
+  size_t total = 8;
+  for (auto& P : pieces) {
+    if (!P.ok) return false;
+    total += P.cp.size();
+  }
+  if (total > (size_t)2147483647 - 16384) return false;
+  L.cp.clear(), L.val.clear();
+  L.cp.reserve(total), L.val.reserve(total);
+  for (int th = 0; th < nthreads; ++th) {
+    const int64_t t0 = ntiles * th / nthreads, t1 = ntiles * (th + 1) / nthreads;
+    const int32_t shift = (int32_t)L.cp.size();
+    for (int64_t t = t0; t < t1; ++t)
+      for (int64_t k = 0; k <= K; ++k) L.base[(size_t)t * (K + 1) + k] += shift;
+    L.cp.insert(L.cp.end(), pieces[(size_t)th].cp.begin(), pieces[(size_t)th].cp.end());
+    L.val.insert(L.val.end(), pieces[(size_t)th].val.begin(), pieces[(size_t)th].val.end());
   }
   for (int i = 0; i < 8; ++i) L.cp.push_back(0), L.val.push_back(0.0);  // 16-byte loads may run past the end
   return true;

@@ -32,11 +32,13 @@ def random_csr32(N, seed):
 rowptr, col, val = random_csr32(N, 12345)
 nnz = int(rowptr[-1])
 ctx = capi.Context()
+t_up = time.perf_counter()
 A = capi.Csr.upload(ctx, N, rowptr, col, val, column_blocks=K)
+t_up = time.perf_counter() - t_up
 b = capi.Basis(ctx, A, N, m)
 b.configure(ortho_mode=capi.ORTHO_BATCHED_ADAPTIVE)
 b.upload(capi.VEC_START, np.random.default_rng(3).standard_normal(N))
-print(f"N={N} nnz={nnz} m={m} operator layout passes={A.column_blocks()}", flush=True)
+print(f"N={N} nnz={nnz} m={m} operator layout {A.layout()} (passes {A.column_blocks()}), upload {t_up:.2f} s", flush=True)
 
 
 def solve():
