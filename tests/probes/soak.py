@@ -19,6 +19,13 @@ for q in range(len(sizes)):
     D = rng.standard_normal((sizes[q], sizes[q]))
     blocks[(q, q)] = (D + D.T) / 2
 Nb = sum(sizes)
+# an operator that takes the column-sorted row tiles (needs >= 2 input slices of 32768 columns)
+Ns = 90_001
+cnt = rng.integers(0, 9, Ns)
+rps = np.zeros(Ns + 1, np.int64); np.cumsum(cnt, out=rps[1:])
+cls = rng.integers(0, Ns, int(rps[-1]))
+cls = cls[np.lexsort((cls, np.repeat(np.arange(Ns), cnt)))].astype(np.int32)
+vls = rng.uniform(-1, 1, cls.size)
 torch.cuda.init()
 free0 = None
 for r in range(rounds):
@@ -44,6 +51,18 @@ for r in range(rounds):
         D = capi.Csr.from_device(ctx, N, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr())
         ed = solver.LanczosEigenSolver(); ed.setDeviceOperator(D).set(minIterations=10, maxIterations=10); ed.compute(); ed.close(); D.close()
         del t
+    S = capi.Csr.upload(ctx, Ns, rps.astype(np.int32), cls, vls, column_blocks=-2)
+    assert S.layout() == "sorted_tiles"
+    sa = solver.ArnoldiEigenSolver()
+    sa.setDeviceOperator(S).set(minIterations=12, maxIterations=12, maxEigenvalues=2)
+    sa.compute(); sa.close()
+    bb = capi.Basis(ctx, S, Ns, 6)
+    bb.upload(capi.VEC_W, rng.standard_normal(Ns)); bb.lanczos_enqueue(5)
+    import ctypes as C
+    h2 = C.c_void_p()
+    assert capi.lib().eigenex_basis_clone(bb.h, C.byref(h2)) == 0  # deep copy of a Krylov state
+    assert capi.lib().eigenex_basis_destroy(h2) == 0
+    bb.close(); S.close()
     zc = solver.LanczosEigenSolver(np.complex128)
     zc.setMatrixMultiplication(lambda x: 2.0 * x, 64).set(maxIterations=5)
     zc.compute()
