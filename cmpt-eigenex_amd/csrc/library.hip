@@ -1350,17 +1350,25 @@ constexpr int64_t kMaxGraphNodes = 20000;
 constexpr int64_t kStackBytesPerGraphNode = 512;
 
 int64_t stack_room_bytes() {
-  pthread_attr_t attr;
-  if (pthread_getattr_np(pthread_self(), &attr) != 0) return 1 << 20;
-  void* base = nullptr;
-  size_t size = 0;
-  const int rc = pthread_attr_getstack(&attr, &base, &size);
-  pthread_attr_destroy(&attr);
-  if (rc != 0 || !base) return 1 << 20;
+  // the stack's extent is looked up once per thread: for the main thread pthread_getattr_np parses /proc/self/maps, which
+  // takes a fraction of a millisecond in a process with thousands of mappings -- as much as a small batch of steps
+  struct Extent {
+    const char* lo = nullptr;
+    size_t size = 0;
+    Extent() {
+      pthread_attr_t attr;
+      if (pthread_getattr_np(pthread_self(), &attr) != 0) return;
+      void* base = nullptr;
+      size_t sz = 0;
+      if (pthread_attr_getstack(&attr, &base, &sz) == 0 && base) lo = static_cast<const char*>(base), size = sz;
+      pthread_attr_destroy(&attr);
+    }
+  };
+  thread_local const Extent ext;
+  if (!ext.lo) return 1 << 20;
   char here;
-  const char* lo = static_cast<const char*>(base);
-  const int64_t room = &here - lo;  // the stack grows down towards `base`
-  return room > 0 && room <= (int64_t)size ? room : 1 << 20;
+  const int64_t room = &here - ext.lo;  // the stack grows down towards `lo`
+  return room > 0 && room <= (int64_t)ext.size ? room : 1 << 20;
 }
 
 int64_t graph_node_limit() { return std::min<int64_t>(kMaxGraphNodes, stack_room_bytes() / kStackBytesPerGraphNode); }
