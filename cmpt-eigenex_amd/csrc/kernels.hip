@@ -38,6 +38,13 @@ __device__ __forceinline__ double block_sum(double x, double* lds4) {
   return (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
 }
 
+// InlineFin, shared part: the same sum as k_reduce_fin (strided per-thread sums, then block_sum), in every workgroup
+__device__ __forceinline__ double inline_fin_sum(const InlineFin& f, double* lds4) {
+  double s = 0.0;
+  for (int b = threadIdx.x; b < f.nblocks; b += kBlock) s += f.partials[b];
+  return block_sum(s, lds4);
+}
+
 // a + b*c with the product rounded first (HIP's __dmul_rn/__dadd_rn are plain operators and get contracted):
 // the shift term is added the way the oracle's row loop adds it
 __device__ __forceinline__ double add_product_nofma(double a, double b, double c) {
@@ -45,6 +52,9 @@ __device__ __forceinline__ double add_product_nofma(double a, double b, double c
   const double p = b * c;
   return a + p;
 }
+
+__device__ __forceinline__ void fin_norm_apply(Ctrl* ctrl, double nrm2, double threshold, int mode, double* beta);
+__device__ __forceinline__ void fin_alpha_apply(Ctrl* ctrl, double val, double* alpha, int first);
 
 __device__ __forceinline__ double2 ld2(const double* p) { return *reinterpret_cast<const double2*>(p); }
 __device__ __forceinline__ void st2(double* p, double2 v) { *reinterpret_cast<double2*>(p) = v; }
@@ -245,8 +255,10 @@ __device__ __forceinline__ void dots_tile(const double* __restrict__ src, const 
 template <bool CPLX, bool RED4, bool DUAL>
 __global__ __launch_bounds__(kBlock) void k_dots(const double* __restrict__ src, ThreeTerm tt, const double* __restrict__ src2,
                                                  ColumnSet cs, int64_t n, int64_t ntiles, double* __restrict__ partials,
-                                                 double* __restrict__ partials2, int pstride, const Ctrl* __restrict__ ctrl) {
+                                                 double* __restrict__ partials2, int pstride, const Ctrl* __restrict__ ctrl,
+                                                 InlineFin fin) {
   extern __shared__ double lds[];  // [DUAL ? 2 : 1][4 waves][ES*ncols]
+  __shared__ double lds4[4];
   if (ctrl->stopped) return;
   constexpr int ES = CPLX ? 2 : 1;
   const int ncols = cs.count + cs.nq;
@@ -254,7 +266,16 @@ __global__ __launch_bounds__(kBlock) void k_dots(const double* __restrict__ src,
   const int wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < (DUAL ? 8 : 4) * nacc; i += kBlock) lds[i] = 0.0;
   __syncthreads();
-  const double a = tt.uk ? *tt.a : 0.0;
+  double a = 0.0;
+  if (fin.partials) {  // alpha_k (lanczos.hpp:448) from the operator kernel's partials; workgroup 0 appends it to the series
+    a = inline_fin_sum(fin, lds4);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      fin.out[0] = a;
+      fin_alpha_apply(fin.ctrl, a, fin.series, fin.mode == kFinishAlphaFirst);
+    }
+  } else if (tt.uk) {
+    a = *tt.a;
+  }
   const double b = (tt.uk && tt.ukm1) ? *tt.b : 0.0;
   double* wave_acc = lds + wave * nacc;
   double* wave_acc2 = lds + (4 + wave) * nacc;
@@ -426,11 +447,22 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int32_t* __restrict__ row
                                                  const double* __restrict__ scale_ptr, double shift,
                                                  double* __restrict__ y, double* __restrict__ u_out, int64_t n,
                                                  int64_t ntiles, double* __restrict__ partials, int spmv_flags,
-                                                 int pass, const Ctrl* __restrict__ ctrl) {
+                                                 int pass, const Ctrl* __restrict__ ctrl, InlineFin fin) {
   __shared__ double prod[kSpmvChunk + kSpmvChunk / 32 + 8];
   __shared__ double lds4[4];
   if (ctrl->stopped) return;
-  const double scale = scale_ptr ? *scale_ptr : 1.0;
+  double scale = scale_ptr ? *scale_ptr : 1.0;
+  if (fin.partials) {  // beta_k, the breakdown test and the scale of the operator input (lanczos.hpp:429-439), taken here
+    const double nrm2 = inline_fin_sum(fin, lds4);
+    const double nrm = sqrt(nrm2);
+    const bool stop = fin.mode == kFinInit ? nrm < fin.threshold : nrm <= fin.threshold;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      fin.out[0] = nrm2;
+      fin_norm_apply(fin.ctrl, nrm2, fin.threshold, fin.mode, fin.series);
+    }
+    if (stop) return;
+    scale = 1.0 / nrm;
+  }
   const int tid = threadIdx.x;
   double dot = 0.0;
   const bool nt = (spmv_flags & 2) != 0;  // flags: bit 0 = XCD-contiguous tiles, bit 1 = non-temporal val/col loads
@@ -1391,7 +1423,7 @@ int grid_for_tiles(int64_t ntiles, int blocks_per_cu) {
 void set_num_cu(int n) { g_num_cu = n > 0 ? n : 256; }
 
 void launch_dots(hipStream_t s, const double* src, ThreeTerm tt, ColumnSet cs, int64_t n, double* partials,
-                 int pstride, int grid, const Ctrl* ctrl, bool cplx, const double* src2, double* partials2) {
+                 int pstride, int grid, const Ctrl* ctrl, bool cplx, const double* src2, double* partials2, const InlineFin* fin) {
   const int ncols = cs.count + cs.nq;
   if (ncols <= 0) return;
   const int64_t ntiles = (n + kTileRows - 1) / kTileRows;
@@ -1400,8 +1432,10 @@ void launch_dots(hipStream_t s, const double* src, ThreeTerm tt, ColumnSet cs, i
     const char* e = getenv("EIGENEX_DOTS_RED4");
     return e ? atoi(e) != 0 : true;
   }();
+  const InlineFin nofin{nullptr, 0, 0, 0.0, nullptr, nullptr, nullptr};
+  const InlineFin f = fin ? *fin : nofin;
 #define EIGENEX_LAUNCH_DOTS(C, R, D) \
-  hipLaunchKernelGGL((k_dots<C, R, D>), dim3(grid), dim3(kBlock), shmem, s, src, tt, src2, cs, n, ntiles, partials, partials2, pstride, ctrl)
+  hipLaunchKernelGGL((k_dots<C, R, D>), dim3(grid), dim3(kBlock), shmem, s, src, tt, src2, cs, n, ntiles, partials, partials2, pstride, ctrl, f)
   if (src2) {
     if (cplx)
       EIGENEX_LAUNCH_DOTS(true, true, true);
@@ -1453,10 +1487,11 @@ void launch_reduce(hipStream_t s, const double* partials, int pstride, int nbloc
 
 void launch_spmv(hipStream_t s, const int32_t* rowptr, const int32_t* col, const double* val, const double* x_ext,
                  const double* scale, double shift, double* y, double* u_out, int64_t n, double* partials, int grid,
-                 const Ctrl* ctrl, int spmv_flags, int pass) {
+                 const Ctrl* ctrl, int spmv_flags, int pass, const InlineFin* fin) {
   const int64_t ntiles = (n + kSpmvRows - 1) / kSpmvRows;
+  const InlineFin nofin{nullptr, 0, 0, 0.0, nullptr, nullptr, nullptr};
   hipLaunchKernelGGL(k_spmv, dim3(grid), dim3(kBlock), 0, s, rowptr, col, val, x_ext, scale, shift, y, u_out, n,
-                     ntiles, partials, spmv_flags, pass, ctrl);
+                     ntiles, partials, spmv_flags, pass, ctrl, fin ? *fin : nofin);
 }
 
 void launch_spmv_sorted(hipStream_t s, const SortedOperatorView& op, const double* x_ext, const double* scale, double shift, double* y,

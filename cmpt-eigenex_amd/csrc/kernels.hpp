@@ -42,6 +42,20 @@ struct ThreeTerm {     // w0 = src - a*u_k - b*u_{k-1}   (lanczos.hpp:403-408); 
   const double* b;
 };
 
+// A step decision that a CONSUMER kernel takes itself from the producer's per-workgroup partial sums (one shard, no
+// communicator, nothing to all-reduce in between): every workgroup repeats the second-stage sum in the fixed order of
+// k_reduce_fin and arrives at the same number, workgroup 0 records it (series, counters, control block).  Saves the
+// dependent one-block launch between producer and consumer: 6 -> 4 launches per Lanczos step.  partials == nullptr: off.
+struct InlineFin {
+  const double* partials;
+  int nblocks;
+  int mode;          // a FinNormMode (consumer = operator kernel) or a FinAlphaMode (consumer = dots kernel)
+  double threshold;
+  double* series;    // beta resp. alpha
+  Ctrl* ctrl;        // the state's control block, writable
+  double* out;       // where k_reduce_fin would have left the sum (hbuf slot)
+};
+
 int grid_for_tiles(int64_t ntiles, int blocks_per_cu);
 void set_num_cu(int n);
 
@@ -49,8 +63,10 @@ void set_num_cu(int n);
 // Vector lengths `n` of dots/update are in DOUBLES (a complex vector of N entries = 2N interleaved doubles);
 // cplx selects conjugate-linear complex arithmetic; complex partials occupy rows 2c (re) and 2c+1 (im).
 // src2 != nullptr: the same columns are also dotted with src2 (no recurrence) in the same pass, sums in partials2
+// fin (real, single source only): alpha_k = sum of the operator kernel's partials, taken inside this kernel (InlineFin)
 void launch_dots(hipStream_t s, const double* src, ThreeTerm tt, ColumnSet cs, int64_t n, double* partials,
-                 int pstride, int grid, const Ctrl* ctrl, bool cplx, const double* src2 = nullptr, double* partials2 = nullptr);
+                 int pstride, int grid, const Ctrl* ctrl, bool cplx, const double* src2 = nullptr, double* partials2 = nullptr,
+                 const InlineFin* fin = nullptr);
 // fused-alpha Lanczos step: h[i] = g[i] - alpha*G[i] from fused = [alpha, -, g (ncoef), G (ncoef)]; alpha joins the series
 void launch_form_h(hipStream_t s, Ctrl* ctrl, const double* fused, int ncoef, double* h, double* alpha, int first);
 // dst = w0 - sum_c h[c]*col_c (sequential in c); partials[block] = partial ||dst||^2
@@ -70,9 +86,10 @@ void launch_reduce(hipStream_t s, const double* partials, int pstride, int nbloc
 // the previous pass), bit 1 (kPassNotLast) = store the raw row sums only (no shift, u_out, dot).
 // bit 2 (kPassSelfNorm): the partials hold ||y||^2 instead of (x*scale).y (adaptive Gram-Schmidt of the Arnoldi step)
 enum { kPassCarry = 1, kPassNotLast = 2, kPassSelfNorm = 4 };
+// fin: beta_k = sqrt(sum of the update kernel's partials), breakdown test and scale = 1/beta_k taken inside this kernel
 void launch_spmv(hipStream_t s, const int32_t* rowptr, const int32_t* col, const double* val, const double* x_ext,
                  const double* scale, double shift, double* y, double* u_out, int64_t n, double* partials, int grid,
-                 const Ctrl* ctrl, int spmv_flags = 0, int pass = 0);
+                 const Ctrl* ctrl, int spmv_flags = 0, int pass = 0, const InlineFin* fin = nullptr);
 // Column-sorted row tiles (real fp64; kernels.hip: k_spmv_sorted): tile t = rows [t*T, (t+1)*T), T = tile_rows, slice k =
 // the k-th range of the operator input (global column order).  Segment (t, k) = entries base[t*(K+1)+k] .. base[t*(K+1)+k+1)
 // of cp/val, sorted by column, padded to a multiple of 4 (val 0, a spare slot); slot = place of the entry in row order

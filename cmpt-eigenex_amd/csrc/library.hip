@@ -236,6 +236,7 @@ struct BasisShard {
   CsrShard* csr = nullptr;
   double *V = nullptr, *Q = nullptr, *v = nullptr, *w = nullptr, *start = nullptr;
   double *partials = nullptr, *hbuf = nullptr, *alpha = nullptr, *beta = nullptr, *H = nullptr;
+  double *pnorm = nullptr, *palpha = nullptr;  // partial sums handed from a producer kernel to the consumer that finalises them (InlineFin)
   double* X = nullptr;  // Ritz vector scratch (ldv x 8), lazy
   Ctrl* ctrl = nullptr;
   Ctrl* ctrl_zero = nullptr;  // always-zero control block for the stand-alone primitives
@@ -283,6 +284,7 @@ struct eigenex_basis_s {
   // Lanczos on more than one shard: alpha of the newest vector travels with the next step's dots (lanczos_call)
   bool fuse_alpha = true;
   bool alpha_pending = false, alpha_pending_first = false;  // hbuf[base_fused()] holds a local, not yet all-reduced alpha
+  bool alpha_pending_inline = false;  // one shard: the operator kernel's alpha partials wait in palpha for the next dots kernel
   int hbuf_len() const { return 8 * maxcols + 64; }
   int base_fused() const { return 4 * maxcols + 16; }  // [alpha (2 slots), g (es*ncols), G (es*ncols)]: one all-reduce
   // offsets (in doubles) into hbuf behind the es*maxcols coefficient entries
@@ -1254,9 +1256,77 @@ inline bool fuses_alpha(const eigenex_basis_s* b) {
 // all-reduce and record an alpha that was left pending (a step without columns to orthogonalise against follows)
 int close_pending_alpha(eigenex_basis_s* b) {
   if (!b->alpha_pending) return 0;
+  if (b->alpha_pending_inline) {  // one shard: the partials of the operator kernel are still waiting for their second stage
+    BasisShard& s = b->sh[0];
+    launch_reduce_fin(b->ctx->stream, s.palpha, s.pstride, s.g_spmv, b->es, s.hbuf + b->slot_alpha(), s.ctrl,
+                      b->alpha_pending_first ? kFinishAlphaFirst : kFinishAlpha, s.alpha, 0.0);
+    b->alpha_pending = b->alpha_pending_inline = false;
+    return 0;
+  }
   CHK(allreduce(b, b->base_fused(), b->es));
   for (auto& s : b->sh) launch_fin_alpha(b->ctx->stream, s.ctrl, s.hbuf + b->base_fused(), s.alpha, b->alpha_pending_first ? 1 : 0, b->cap);
   b->alpha_pending = false;
+  return 0;
+}
+
+// One shard, plain real CSR, batched scheme: the two one-block launches of a Lanczos step (norm -> beta/scale/breakdown, alpha ->
+// series) are taken over by their consumer kernels (kernels.hpp: InlineFin): k_dots sums the operator's alpha partials
+// itself, k_spmv sums the update's norm partials itself -- 4 launches per step instead of 6, same sums in the same
+// order, same decisions.  Matters where a step is launch-bound (32^3: 29 -> 21 us per step); nothing at 512^3.
+inline bool inlines_fin(const eigenex_basis_s* b) {
+  static const bool off = std::getenv("EIGENEX_NO_INLINE_FIN") != nullptr;
+  if (off || !decides_locally(b) || !b->csr || b->es != 1) return false;
+  const CsrShard& m = b->csr->sh[0];
+  return !m.blocked && !m.sorted && m.passes == 1 && (b->ortho_mode == EIGENEX_ORTHO_BATCHED || b->ortho_mode == EIGENEX_ORTHO_BATCHED_ADAPTIVE);
+}
+
+int lanczos_step_inline(eigenex_basis_s* b, int k, int first, int stride, int count, int nq, bool last_in_batch) {
+  eigenex_context_s* c = b->ctx;
+  hipStream_t st = c->stream;
+  BasisShard& s = b->sh[0];
+  const CsrShard* m = s.csr;
+  const int ncols = count + nq;
+  const ThreeTerm tt{s.V + (int64_t)k * s.ldd, k > 0 ? s.V + (int64_t)(k - 1) * s.ldd : nullptr, s.alpha + k, s.beta + (k > 0 ? k - 1 : 0)};
+  // dots of w0 = v - alpha_k u_k - beta_{k-1} u_{k-1}; a pending alpha_k is finalised inside the (first) dots launch
+  const int chunk = kDotsMaxAcc;
+  for (int c0 = 0; c0 < ncols; c0 += chunk) {
+    const int nc = std::min(chunk, ncols - c0);
+    const int v0 = std::min(c0, count), v1 = std::min(c0 + nc, count);
+    const int q0 = std::max(c0 - count, 0), q1 = std::max(c0 + nc - count, 0);
+    InlineFin fa{s.palpha, s.g_spmv, b->alpha_pending_first ? kFinishAlphaFirst : kFinishAlpha, 0.0, s.alpha, s.ctrl, s.hbuf + b->slot_alpha()};
+    const bool take_alpha = b->alpha_pending && c0 == 0;
+    ProfScope ps(c, EIGENEX_K_DOTS, 8.0 * s.nd * nc + 8.0 * s.nd);
+    LAUNCH_BEGIN();
+    launch_dots(st, s.v, tt, colset(s, first + v0 * stride, stride, v1 - v0, q0, q1 - q0), s.nd, s.partials + (int64_t)c0 * s.pstride, s.pstride,
+                s.g_vec, s.ctrl, false, nullptr, nullptr, take_alpha ? &fa : nullptr);
+    LAUNCHCHK("k_dots");
+    if (take_alpha) b->alpha_pending = b->alpha_pending_inline = false;
+  }
+  {
+    ProfScope ps(c, EIGENEX_K_SMALL, 0.0);
+    launch_reduce(st, s.partials, s.pstride, s.g_vec, ncols, s.hbuf, s.ctrl);
+  }
+  {
+    ProfScope ps(c, EIGENEX_K_UPDATE, 8.0 * s.nd * ncols + 24.0 * s.nd + 32.0 * s.nd);
+    LAUNCH_BEGIN();
+    launch_update(st, s.v, s.w, tt, colset(s, first, stride, count, 0, nq), s.hbuf, s.nd, s.pnorm, s.g_vec, s.ctrl, false);
+    LAUNCHCHK("k_update");
+  }
+  // operator: beta_k, breakdown test and scale from the update's partials inside the kernel; alpha_{k+1} partials to palpha
+  {
+    InlineFin fn{s.pnorm, s.g_vec, kFinLanczos, b->threshold, s.beta, s.ctrl, s.hbuf + b->slot_nrm()};
+    ProfScope ps(c, EIGENEX_K_SPMV, 12.0 * m->nnz + 4.0 * (m->nloc + 1) + 32.0 * s.nd + 16.0 * s.nd);
+    launch_spmv(st, m->rowptr, m->col, m->val, s.w, nullptr, b->shift, s.v, s.V + (int64_t)(k + 1) * s.ldd, m->nloc, s.palpha, s.g_spmv, s.ctrl,
+                s.spmv_flags, 0, &fn);
+  }
+  if (last_in_batch) {
+    ProfScope ps(c, EIGENEX_K_SMALL, 0.0);
+    launch_reduce_fin(st, s.palpha, s.pstride, s.g_spmv, 1, s.hbuf + b->slot_alpha(), s.ctrl, kFinishAlpha, s.alpha, 0.0);
+  } else {
+    b->alpha_pending = b->alpha_pending_inline = true;
+    b->alpha_pending_first = false;
+  }
+  b->h_nvec++;
   return 0;
 }
 
@@ -1283,7 +1353,8 @@ int lanczos_call(eigenex_basis_s* b, bool last_in_batch) {
   if (b->h_nvec >= b->cap) return fail(EIGENEX_ERR_STATE, "basis capacity exhausted");
   int first, stride, count, nq;
   lanczos_columns(k, b->interval, b->nq, &first, &stride, &count, &nq);
-  if (b->alpha_pending && count + nq == 0) CHK(close_pending_alpha(b));  // no dots pass to ride on
+  if (inlines_fin(b) && count + nq > 0) return lanczos_step_inline(b, k, first, stride, count, nq, last_in_batch);
+  if (b->alpha_pending && (count + nq == 0 || b->alpha_pending_inline)) CHK(close_pending_alpha(b));  // no dots pass to ride on
   const bool fused = b->alpha_pending;
   bool merged = false;
   CHK(enq_orthogonalize(b, EIGENEX_VEC_V, EIGENEX_VEC_W, true, k, first, stride, count, nq, false, false, kFinLanczos, &merged, fused));
@@ -2213,7 +2284,7 @@ int eigenex_basis_destroy(eigenex_basis_t b) {
   (void)hipStreamSynchronize(b->ctx->stream);
   drop_step_graphs(b);
   for (auto& s : b->sh) {
-    for (void* p : {(void*)s.V, (void*)s.Q, (void*)s.v, (void*)s.w, (void*)s.start, (void*)s.partials, (void*)s.hbuf, (void*)s.alpha,
+    for (void* p : {(void*)s.V, (void*)s.Q, (void*)s.v, (void*)s.w, (void*)s.start, (void*)s.partials, (void*)s.pnorm, (void*)s.hbuf, (void*)s.alpha,
                     (void*)s.beta, (void*)s.H, (void*)s.X, (void*)s.ctrl, (void*)s.ctrl_zero, (void*)s.ctrl_pass2})
       if (p) (void)hipFree(p);
   }
@@ -2287,6 +2358,8 @@ int eigenex_basis_create_ex(eigenex_context_t c, eigenex_csr_t csr, int64_t n_gl
                            grid_for_tiles((s.nloc + kSpmvRows - 1) / kSpmvRows, kMaxBlocksPerCu));
       const int rows = 4 * std::max(b->maxcols, 8) + 4;  // two dot sets of a complex column set (fused-alpha step)
       HIPCHK(hipMalloc(&s.partials, sizeof(double) * (size_t)s.pstride * rows));
+      HIPCHK(hipMalloc(&s.pnorm, sizeof(double) * (size_t)s.pstride * 2));
+      s.palpha = s.pnorm + s.pstride;
       HIPCHK(hipMalloc(&s.hbuf, sizeof(double) * b->hbuf_len()));
       HIPCHK(hipMemsetAsync(s.hbuf, 0, sizeof(double) * b->hbuf_len(), c->stream));
       HIPCHK(hipMalloc(&s.alpha, sizeof(double) * (capacity + 2)));
@@ -2456,7 +2529,7 @@ int eigenex_basis_clear(eigenex_basis_t b) {
   for (auto& s : b->sh) HIPCHK(hipMemsetAsync(s.ctrl, 0, sizeof(Ctrl), b->ctx->stream));
   b->started = false;
   b->h_nvec = 0;
-  b->alpha_pending = false;
+  b->alpha_pending = b->alpha_pending_inline = false;
   return 0;
 }
 

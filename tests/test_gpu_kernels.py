@@ -749,3 +749,46 @@ def test_column_sorted_row_tiles_bit_exact(capi, shards):
     with pytest.raises(capi.EigenexError, match="column-sorted row tiles"):
         capi.Csr.upload(ctx, 1000, np.arange(1001, dtype=np.int32), np.arange(1000, dtype=np.int32), np.ones(1000), column_blocks=-2)
     ctx.close()
+
+
+def test_finalisers_inside_their_consumer_kernels_change_nothing(capi):
+    """One shard, plain real CSR, batched scheme: beta/scale/breakdown are taken by the operator kernel from the update's
+    partials and alpha by the next dots kernel from the operator's partials (InlineFin: 4 launches per step instead of
+    6).  Same sums in the same order: coefficients, counters, breakdown behaviour and the basis are bit-identical to
+    the separate one-block finalisers; checked here against the oracle, through the bookkeeping invariants after every
+    batch, and through independence of where the batch boundaries fall (the last call of a batch closes its alpha with
+    the separate launch)."""
+    n, m = 14, 30
+    N = n ** 3
+    rowptr, col, val = cref.laplacian3d(n)
+    init = np.random.default_rng(8).standard_normal(N)
+    ref, ok = _lanczos_ref(rowptr, col, val, init, m + 1, shift=0.3)
+    ctx = capi.Context()
+    A = capi.Csr.upload(ctx, N, rowptr, col, val, column_blocks=0)
+    assert A.layout() == "csr"
+    runs = []
+    for batches in ((m + 1,), (1, 1, 5, m - 6), (2,) * 15 + (1,)):
+        b = capi.Basis(ctx, A, N, m + 1)
+        b.configure(0.3, 1e-12, 1, capi.ORTHO_BATCHED)
+        b.upload(capi.VEC_W, init)
+        for nb in batches:
+            b.lanczos_enqueue(nb)
+            st, alpha, beta = b.lanczos_state()
+            assert st.nalpha == st.nvec and st.nbeta == st.nvec - 1 and st.calls_true == st.nvec and st.iterations == st.nvec - 1
+        assert st.nvec == m + 1 and st.stopped == 0
+        np.testing.assert_allclose(alpha, ref.alpha, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(beta, ref.beta, rtol=0, atol=1e-12)
+        runs.append((alpha, beta, b.download(capi.VEC_COL(m))))
+        b.close()
+    for r in runs[1:]:  # the batch boundaries (where alpha is closed by its own launch) do not show in the numbers
+        for x, y in zip(r, runs[0]):
+            np.testing.assert_array_equal(x, y)
+    # breakdown inside the operator kernel's own decision: invariant subspace of dimension 2
+    A2 = capi.Csr.upload(ctx, 4, np.arange(5, dtype=np.int32), np.arange(4, dtype=np.int32), np.array([1.0, 2.0, 3.0, 4.0]))
+    b = capi.Basis(ctx, A2, 4, 6)
+    b.upload(capi.VEC_W, np.array([1.0, 1.0, 0.0, 0.0]))
+    b.lanczos_enqueue(5)
+    st, alpha, beta = b.lanczos_state()
+    assert (st.nvec, st.nalpha, st.nbeta, st.stopped, st.calls_true, st.iterations) == (2, 2, 2, 1, 2, 1)
+    assert beta[-1] <= 1e-12
+    ctx.close()
