@@ -274,3 +274,21 @@ def test_lookahead_depth_is_rank_invariant(tmp_path):
     out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert out.returncode == 0, (out.stdout + out.stderr).decode()[-2000:]
     assert b"all checks passed" in out.stdout
+
+
+def test_plain_c99_host_of_the_gpu_free_entry_points(built, tmp_path):
+    """include/eigenex_hip.h is a C header: a C99 program (-pedantic) drives the partition, the shard plan (local numbering,
+    halo slots, request/send lists) and the collective schedule -- the calls a cgo / JNI / ctypes binding makes -- and
+    gets error codes, not crashes, for bad input (tests/cpp/c_host_plan.c)."""
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    exe = str(tmp_path / "c_host_plan")
+    lib = os.path.join(ROOT, "cmpt-eigenex_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "c_host_plan.c"), "-o", exe, "-L", lib, "-leigenex_hip", "-Wl,-rpath," + lib])
+    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert out.returncode == 0, (out.stdout + out.stderr).decode()[-2000:]
+    assert b"c host: ok" in out.stdout
