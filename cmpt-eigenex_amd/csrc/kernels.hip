@@ -255,7 +255,7 @@ __device__ __forceinline__ void dots_tile(const double* __restrict__ src, const 
 template <bool CPLX, bool RED4, bool DUAL>
 __global__ __launch_bounds__(kBlock) void k_dots(const double* __restrict__ src, ThreeTerm tt, const double* __restrict__ src2,
                                                  ColumnSet cs, int64_t n, int64_t ntiles, double* __restrict__ partials,
-                                                 double* __restrict__ partials2, int pstride, const Ctrl* __restrict__ ctrl,
+                                                 double* __restrict__ partials2, int pstride, const Ctrl* ctrl,  // no __restrict__: fin.ctrl aliases it
                                                  InlineFin fin) {
   extern __shared__ double lds[];  // [DUAL ? 2 : 1][4 waves][ES*ncols]
   __shared__ double lds4[4];
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int32_t* __restrict__ row
                                                  const double* __restrict__ scale_ptr, double shift,
                                                  double* __restrict__ y, double* __restrict__ u_out, int64_t n,
                                                  int64_t ntiles, double* __restrict__ partials, int spmv_flags,
-                                                 int pass, const Ctrl* __restrict__ ctrl, InlineFin fin) {
+                                                 int pass, const Ctrl* ctrl, InlineFin fin) {  // no __restrict__ on ctrl: fin.ctrl aliases it
   __shared__ double prod[kSpmvChunk + kSpmvChunk / 32 + 8];
   __shared__ double lds4[4];
   if (ctrl->stopped) return;
