@@ -16,8 +16,12 @@
  * order the HIP SpMV kernel reproduces bit for bit (build with -ffp-contract=off).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
- * this library.  nthreads > 1 (OpenMP) exists for the cpu_baseline leg only;
- * parity tests always use nthreads = 1.
+ * this library.  nthreads > 1 (OpenMP) splits the element-wise loops and the row loop of
+ * the CSR product (results unchanged) and turns every dot product into per-thread
+ * running sums added at the end (a rounding-level change, like any summation order):
+ * used by the cpu_baseline leg and by the tests at BASELINE's full sizes
+ * (tests/test_gpu_fullsize.py: 128^3, 10^6 x 32, 512^3), where the tolerances are stated
+ * with that in mind; every other parity test uses nthreads = 1.
  *
  * Pinning: see oracle/krylov_oracle.py (known answers of the reference's samples;
  * tests/test_oracle_golden.py also checks this file against the numpy restatement).
