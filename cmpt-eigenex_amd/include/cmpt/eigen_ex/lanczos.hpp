@@ -895,8 +895,12 @@ class LanczosEigenSolver {
   Index mainCalculation_() {
     info_ = Success;
     if (matrixHeight() <= 0 || !lanczosBase_.hasOperator()) info_ = InvalidInput;
+    // reference :741: es_tri_.computeFromTridiagonal(empty, empty) -- also when continueToCompute() re-enters with a
+    // computed state: the first pass then logs nothing and cannot report convergence, so a continued run always makes
+    // at least one more step unless it is at maxIterations or the Krylov space is exhausted (found by
+    // tests/test_gpu_solver_fuzz.py: recomputing T's spectrum here logged the last Ritz value twice and "converged")
     triValues_.clear();
-    solveTridiagonal_();
+    triStale_ = false;
     if (maxIterations_ != unlimited) lanczosBase_.reserveBasis(maxIterations_ + 1);  // m iterations -> m+1 vectors
     lanczosBase_.setSpeculationBound(1);  // the certain calls are not speculation, and nothing may run beyond them yet
     lanczosBase_.prefetchLanczosSteps(certainCalls_());
