@@ -464,7 +464,7 @@ class Csr:
     def layout(self) -> str:
         v = C.c_int()
         _chk(lib().eigenex_csr_layout(self.h, C.byref(v)))
-        return ("csr", "column_blocked", "sorted_tiles", "dense_blocks")[v.value]
+        return ("csr", "column_blocked", "sorted_tiles", "dense_blocks", "split_tiles")[v.value]
 
     def column_blocks(self) -> int:
         k = C.c_int()

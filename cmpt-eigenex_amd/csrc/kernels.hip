@@ -725,6 +725,114 @@ __global__ __launch_bounds__(kSortBlock) void k_spmv_sorted(SortedOperatorView o
   }
 }
 
+// ---------------------------------------------------------------------------
+// Split tiles (split_layout.hpp): one workgroup per (row tile of up to 16384 rows, column group); partial row sums in LDS.
+// Per chunk of <= 4096 column-sorted entries: 4 entries per lane, gathers, products rounded, acc[row] += product (no two
+// entries of a chunk share a row: plain read-add-write, no atomics), one barrier.  The entry streams run two chunks ahead,
+// the gathers one chunk ahead of the adds.
+// ---------------------------------------------------------------------------
+struct SplitRegs {
+  uint4 c;
+  double2 v01, v23;
+  int nvalid;    // 0..4 entries of this lane in the chunk
+  int64_t pos0;  // position of relative column 0
+};
+__device__ __forceinline__ void split_load(SplitRegs& g, const SplitOperatorView& op, int c, int c1, int tid) {
+  g.nvalid = 0;
+  if (c >= c1) return;
+  const int4 d = op.chunk[c];
+  const int q = d.x + 4 * tid;
+  g.nvalid = min(4, max(0, d.y - q));
+  g.pos0 = d.z;
+  if (g.nvalid > 0) {
+    g.c = *reinterpret_cast<const uint4*>(op.cp + q);
+    g.v01 = nt_ld_d2(op.val + q);
+    g.v23 = nt_ld_d2(op.val + q + 2);
+  }
+}
+__device__ __forceinline__ int64_t split_index(const SplitOperatorView& op, int64_t pos0, unsigned c) {
+  const int64_t p = pos0 + (c & ((1u << kSplitRelBits) - 1));
+  return p < op.n_low ? op.npad + p : (p < op.n_low + op.nloc ? p - op.n_low : op.npad + p - op.nloc);
+}
+__device__ __forceinline__ void split_gather(double (&x)[4], const SplitRegs& g, const SplitOperatorView& op,
+                                             const double* __restrict__ x_ext) {
+  x[0] = x[1] = x[2] = x[3] = 0.0;
+  if (g.nvalid > 0) x[0] = x_ext[split_index(op, g.pos0, g.c.x)];
+  if (g.nvalid > 1) x[1] = x_ext[split_index(op, g.pos0, g.c.y)];
+  if (g.nvalid > 2) x[2] = x_ext[split_index(op, g.pos0, g.c.z)];
+  if (g.nvalid > 3) x[3] = x_ext[split_index(op, g.pos0, g.c.w)];
+}
+// acc[row] += product: the product is rounded first (a separate multiply), the add is an LDS atomic that returns nothing
+// (ds_add_f64) -- cheaper than read-add-write, and no two entries of a chunk share a row, so nothing about it is unordered
+__device__ __forceinline__ void split_add1(double* a, double p) {
+  (void)__hip_atomic_fetch_add(a, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void split_add(const SplitRegs& g, const double (&x)[4], double scale, double* acc) {
+  if (g.nvalid > 0) split_add1(acc + (g.c.x >> kSplitRelBits), g.v01.x * (x[0] * scale));
+  if (g.nvalid > 1) split_add1(acc + (g.c.y >> kSplitRelBits), g.v01.y * (x[1] * scale));
+  if (g.nvalid > 2) split_add1(acc + (g.c.z >> kSplitRelBits), g.v23.x * (x[2] * scale));
+  if (g.nvalid > 3) split_add1(acc + (g.c.w >> kSplitRelBits), g.v23.y * (x[3] * scale));
+}
+
+// DEPTH = chunks whose gathers are in flight ahead of the adds (the entry streams run one chunk further ahead)
+template <int DEPTH>
+__global__ __launch_bounds__(kSplitBlock) void k_spmv_split(SplitOperatorView op, const double* __restrict__ x_ext,
+                                                           const double* __restrict__ scale_ptr, const Ctrl* __restrict__ ctrl) {
+  extern __shared__ double lds_acc[];  // tile_rows partial row sums
+  if (ctrl->stopped) return;
+  const double scale = scale_ptr ? *scale_ptr : 1.0;
+  const int tid = threadIdx.x, T = op.tile_rows;
+  const int wg = blockIdx.x, tile = wg / op.groups, grp = wg - tile * op.groups;
+  const int c0 = op.wg_chunk[wg], c1 = op.wg_chunk[wg + 1];
+  SplitRegs r[DEPTH + 2];
+  double x[DEPTH + 1][4];
+#pragma unroll
+  for (int d = 0; d <= DEPTH; ++d) split_load(r[d], op, c0 + d, c1, tid);
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) split_gather(x[d], r[d], op, x_ext);
+  for (int i = tid; i < T; i += kSplitBlock) lds_acc[i] = 0.0;
+  __syncthreads();
+  for (int c = c0; c < c1; ++c) {
+    split_load(r[DEPTH + 1], op, c + DEPTH + 1, c1, tid);
+    split_gather(x[DEPTH], r[DEPTH], op, x_ext);
+    split_add(r[0], x[0], scale, lds_acc);
+    __syncthreads();  // the next chunk may hold the same rows
+#pragma unroll
+    for (int d = 0; d <= DEPTH; ++d) r[d] = r[d + 1];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) x[d][i] = x[d + 1][i];
+  }
+  const int64_t r0w = (int64_t)tile * T;
+  double* dst = op.part + (int64_t)grp * op.part_stride + r0w;
+  for (int i = tid; i < T; i += kSplitBlock)
+    if (r0w + i < op.nloc) dst[i] = lds_acc[i];
+}
+
+__global__ __launch_bounds__(kBlock) void k_split_combine(const double* __restrict__ part, int64_t part_stride, int groups,
+                                                         const double* __restrict__ x_ext, const double* __restrict__ scale_ptr,
+                                                         double shift, double* __restrict__ y, double* __restrict__ u_out, int64_t n,
+                                                         double* __restrict__ partials, int pass, const Ctrl* __restrict__ ctrl) {
+  __shared__ double lds4[4];
+  if (ctrl->stopped) return;
+  const double scale = scale_ptr ? *scale_ptr : 1.0;
+  double dot = 0.0;
+  for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
+    double yr = part[r];
+    for (int g = 1; g < groups; ++g) yr = yr + part[(int64_t)g * part_stride + r];  // ascending group order
+    const double xr = x_ext[r] * scale;
+    if (shift != 0.0) yr = add_product_nofma(yr, shift, xr);  // lanczos.hpp:390-392
+    y[r] = yr;
+    if (u_out) u_out[r] = xr;
+    dot = (pass & kPassSelfNorm) ? fma(yr, yr, dot) : fma(xr, yr, dot);
+  }
+  if (partials) {
+    dot = block_sum(dot, lds4);
+    if (threadIdx.x == 0) partials[blockIdx.x] = dot;
+  }
+}
+
 // Complex fp64 variant (the scalar type of the reference's own samples): entries, x and
 // products are 16-byte (re, im) pairs; 1024 products per LDS chunk.  Same two phases, same
 // stored-order accumulation; products use separate multiplies and adds (no contraction),
@@ -1513,6 +1621,23 @@ void launch_spmv_sorted(hipStream_t s, const SortedOperatorView& op, const doubl
     hipLaunchKernelGGL(k_spmv_sorted<2>, grid, block, shmem, s, op, x_ext, scale, shift, y, u_out, n, ntiles, partials, pass, ctrl);
   else
     hipLaunchKernelGGL(k_spmv_sorted<1>, grid, block, shmem, s, op, x_ext, scale, shift, y, u_out, n, ntiles, partials, pass, ctrl);
+}
+
+int split_combine_grid(int64_t n) { return grid_for_tiles((n + 2 * kBlock - 1) / (2 * kBlock), 8); }
+
+void launch_spmv_split(hipStream_t s, const SplitOperatorView& op, const double* x_ext, const double* scale, double shift, double* y,
+                       double* u_out, int64_t n, double* partials, const Ctrl* ctrl, int pass) {
+  // gathers one chunk ahead, LDS atomics (ds_add_f64, nothing returned): measured 121 us on BASELINE config 3 against 125 / 123 us
+  // two / three chunks ahead and 126-130 us with read-add-write (scripts/microbench/split_tiles.hip)
+  static const auto kernel = k_spmv_split<1>;
+  static const bool attr_set = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int)(sizeof(double) * kSplitMaxTileRows)) == hipSuccess;
+  (void)attr_set;
+  const int64_t ntiles = (n + op.tile_rows - 1) / op.tile_rows;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)(ntiles * op.groups)), dim3(kSplitBlock), sizeof(double) * op.tile_rows, s, op, x_ext,
+                     scale, ctrl);
+  hipLaunchKernelGGL(k_split_combine, dim3(split_combine_grid(n)), dim3(kBlock), 0, s, op.part, op.part_stride, op.groups, x_ext, scale,
+                     shift, y, u_out, n, partials, pass, ctrl);
 }
 
 int sorted_grid(int64_t n, int tile_rows) { return grid_for_tiles((n + tile_rows - 1) / tile_rows, 1); }

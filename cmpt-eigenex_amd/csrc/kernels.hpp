@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "split_layout.hpp"
+
 namespace eigenex {
 
 // Device-resident control block of one Krylov state (replicated on every shard:
@@ -114,6 +116,24 @@ struct SortedOperatorView {
 int sorted_grid(int64_t n, int tile_rows);
 void launch_spmv_sorted(hipStream_t s, const SortedOperatorView& op, const double* x_ext, const double* scale, double shift, double* y,
                         double* u_out, int64_t n, double* partials, const Ctrl* ctrl, int pass = 0);
+// Split tiles (real fp64; kernels.hip: k_spmv_split + k_split_combine; layout and reasons in split_layout.hpp): workgroup
+// w = tile*groups + group walks the chunks wg_chunk[w] .. wg_chunk[w+1); chunk c = entries chunk[4c] .. chunk[4c+1) of cp/val,
+// chunk[4c+2] = position (global column order) of its first column; cp = row in tile << 18 | position - that.  The
+// partial row sums of group g go to part[g*part_stride + row]; k_split_combine adds them in ascending group order and does
+// what the other operator kernels do in their epilogue (shift, u_out, partial dot).
+struct SplitOperatorView {
+  const int32_t* wg_chunk;
+  const int4* chunk;
+  const uint32_t* cp;
+  const double* val;
+  int groups, tile_rows;
+  int64_t n_low, npad, nloc;  // position -> index into the operator input, as for SortedOperatorView
+  double* part;
+  int64_t part_stride;
+};
+int split_combine_grid(int64_t n);
+void launch_spmv_split(hipStream_t s, const SplitOperatorView& op, const double* x_ext, const double* scale, double shift, double* y,
+                       double* u_out, int64_t n, double* partials, const Ctrl* ctrl, int pass = 0);
 // Block-sparse operator (the reference's BlockTensor<Scalar,2> layout, block_tensor.hpp:1193-1206, real or complex fp64):
 // 8 bytes per stored entry plus one column index per block COLUMN (4/rows bytes per entry) instead of CSR's 12.
 //   group g = the rows of one sector that this shard owns, rows grow0[g] .. grow0[g+1].  Its blocks, side by side,

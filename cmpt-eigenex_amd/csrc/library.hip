@@ -204,6 +204,13 @@ struct CsrShard {
   uint16_t* s_off = nullptr;
   int s_width = 0;
   int64_t s_nlow = 0;
+  // split tiles (kernels.hpp: SplitOperatorView; split_layout.hpp) instead of rowptr/col: partial row sums per column group,
+  // added in a second kernel -- the one layout that re-associates a row's sum
+  bool split = false;
+  int sp_groups = 0;
+  int32_t *sp_wg = nullptr, *sp_chunk = nullptr;
+  uint32_t* sp_cp = nullptr;
+  double* sp_part = nullptr;
   // block-sparse format (eigenex_block_upload; kernels.hpp: BlockOperatorView) instead of rowptr/col/val
   bool blocked = false;
   double* bval = nullptr;
@@ -371,7 +378,7 @@ void free_csr_shard(CsrShard& s) {
   if (s.send_idx) (void)hipFree(s.send_idx);
   if (s.sendbuf) (void)hipFree(s.sendbuf);
   for (void* p : {(void*)s.bval, (void*)s.gent, (void*)s.gcol, (void*)s.cols, (void*)s.grow0, (void*)s.rowgrp, (void*)s.s_base,
-                  (void*)s.s_cp, (void*)s.s_off})
+                  (void*)s.s_cp, (void*)s.s_off, (void*)s.sp_wg, (void*)s.sp_chunk, (void*)s.sp_cp, (void*)s.sp_part})
     if (p) (void)hipFree(p);
   s = CsrShard();
 }
@@ -691,10 +698,43 @@ int build_shard_host(eigenex_context_s* c, int64_t n_global, int gshard, const i
   const double* vsrc = val + p0 * es;
   std::vector<uint8_t> blk;
   std::vector<double> bval;
-  // Layout for scattered gathers over an input that does not fit L2: column-sorted row tiles when eligible
-  // (column_blocks -1: automatic, -2: asked for), else column-blocked passes (2..16: asked for)
-  if (column_blocks == -2 || (column_blocks == -1 && es == 1 && (s.nloc + s.nhalo) * 8 > kSliceBytes && s.nnz / std::max<int64_t>(s.nloc, 1) >= 6 &&
-                              gathers_scattered(s, lcol, lrp))) {
+  // Layouts for scattered gathers over an input that does not fit L2.  Split tiles (column_blocks -3: asked for; -1: taken
+  // when a tile has >= 3 gathers per 128-byte input line, unless EIGENEX_EXACT_ROW_SUMS is set): the fastest, row sums
+  // re-associated.  Column-sorted row tiles (-2: asked for; -1: when eligible): bit-identical to the row loop.  Else
+  // column-blocked passes (2..16: asked for).
+  const bool scattered = column_blocks == -1 && es == 1 && (s.nloc + s.nhalo) * 8 > kSliceBytes && s.nnz / std::max<int64_t>(s.nloc, 1) >= 6 &&
+                         gathers_scattered(s, lcol, lrp);
+  if (column_blocks == -3 || scattered) {
+    static const bool exact = std::getenv("EIGENEX_EXACT_ROW_SUMS") != nullptr;
+    int T = 0, G = 0;
+    bool want = false;
+    if (column_blocks == -3) {
+      if (es != 1) return fail(EIGENEX_ERR_ARG, "split tiles need a real operator");
+      for (int wgs : {240, 64, 8, 1})
+        if ((want = split_geometry(s.nloc, wgs, 256, &T, &G))) break;
+    } else if (!exact && split_geometry(s.nloc, 240, 4096, &T, &G)) {
+      want = (double)T * (double)s.nnz / (double)s.nloc * 16.0 >= 3.0 * (double)(s.nloc + s.nhalo);
+    }
+    SplitLayout L;
+    const GlobalOrder order(s);
+    if (want && build_split_layout(s.nloc, s.nloc + s.nhalo, lrp.data(), lcol.data(), vsrc, order, T, G, L)) {
+      s.split = true;
+      s.sp_groups = L.G;
+      s.tile_rows = L.T;
+      s.s_nlow = order.n_low;
+      CHK(upload_vec(c, &s.sp_wg, L.wg_chunk, 8));
+      CHK(upload_vec(c, &s.sp_chunk, L.chunk, 8));
+      CHK(upload_vec(c, &s.sp_cp, L.cp, 8));
+      CHK(upload_vec(c, &s.val, L.val, 8));
+      HIPCHK(hipMalloc(&s.sp_part, sizeof(double) * (size_t)s.npad * L.G));
+      HIPCHK(hipMemsetAsync(s.sp_part, 0, sizeof(double) * (size_t)s.npad * L.G, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      return 0;
+    }
+    if (column_blocks == -3)
+      return fail(EIGENEX_ERR_ARG, "split tiles: a row has too many entries in one column group, or the shard is empty");
+  }
+  if (column_blocks == -2 || scattered) {
     static const bool off = std::getenv("EIGENEX_NO_SORTED_TILES") != nullptr;
     SortedLayout L;
     if (!(off && column_blocks == -1) && build_sorted_layout(s, lcol, lrp, vsrc, L)) {
@@ -714,7 +754,7 @@ int build_shard_host(eigenex_context_s* c, int64_t n_global, int gshard, const i
       return fail(EIGENEX_ERR_ARG, "column-sorted row tiles need a real operator whose rows meet the 256 KB input slices in stored order, "
                                    "2..64 slices and fewer than 8188 entries per (1024-row tile, slice)");
   }
-  s.passes = choose_column_blocks(s, lcol, lrp, column_blocks == -2 ? -1 : column_blocks, blk);
+  s.passes = choose_column_blocks(s, lcol, lrp, column_blocks <= -2 ? -1 : column_blocks, blk);
   if (s.passes > 1) {
     // stable counting sort of the entries by (pass, row): pass k's entries are contiguous, rows keep stored order
     const int K = s.passes;
@@ -1134,6 +1174,12 @@ int enq_orthogonalize(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_t
 void launch_operator(hipStream_t st, const CsrShard* m, int es, const double* x_ext, const double* scale, double shift,
                      double shift_im, double* y, double* u_out, double* partials, int pstride, int grid, const Ctrl* ctrl,
                      int flags, int last_pass_flags = 0) {
+  if (m->split) {
+    const SplitOperatorView op{m->sp_wg, reinterpret_cast<const int4*>(m->sp_chunk), m->sp_cp, m->val, m->sp_groups, m->tile_rows,
+                               m->s_nlow, m->npad, m->nloc, m->sp_part, m->npad};
+    launch_spmv_split(st, op, x_ext, scale, shift, y, u_out, m->nloc, partials, ctrl, last_pass_flags);
+    return;
+  }
   if (m->sorted) {
     const SortedOperatorView op{m->s_base, m->s_cp, m->val, m->s_off, m->nslices, m->tile_rows, m->s_width, m->s_nlow, m->npad, m->nloc};
     launch_spmv_sorted(st, op, x_ext, scale, shift, y, u_out, m->nloc, partials, ctrl, last_pass_flags);
@@ -1277,7 +1323,7 @@ inline bool inlines_fin(const eigenex_basis_s* b) {
   static const bool off = std::getenv("EIGENEX_NO_INLINE_FIN") != nullptr;
   if (off || !decides_locally(b) || !b->csr || b->es != 1) return false;
   const CsrShard& m = b->csr->sh[0];
-  return !m.blocked && !m.sorted && m.passes == 1 && (b->ortho_mode == EIGENEX_ORTHO_BATCHED || b->ortho_mode == EIGENEX_ORTHO_BATCHED_ADAPTIVE);
+  return !m.blocked && !m.sorted && !m.split && m.passes == 1 && (b->ortho_mode == EIGENEX_ORTHO_BATCHED || b->ortho_mode == EIGENEX_ORTHO_BATCHED_ADAPTIVE);
 }
 
 int lanczos_step_inline(eigenex_basis_s* b, int k, int first, int stride, int count, int nq, bool last_in_batch) {
@@ -1448,7 +1494,7 @@ int64_t graph_node_limit() { return std::min<int64_t>(kMaxGraphNodes, stack_room
 int64_t launches_upper_bound(const eigenex_basis_s* b, int ncalls) {
   int passes = 1;
   if (b->csr)
-    for (auto& s : b->csr->sh) passes = std::max(passes, s.passes);
+    for (auto& s : b->csr->sh) passes = std::max(passes, s.split ? 2 : s.passes);  // split tiles: two launches per application
   int64_t total = 0;
   int nvec = b->h_nvec;
   for (int i = 0; i < ncalls; ++i) {
@@ -1952,7 +1998,7 @@ int eigenex_profile_get(eigenex_context_t c, int kind, int64_t* launches, double
 // ---- operator ---------------------------------------------------------------
 static int csr_upload_impl(eigenex_context_t c, int64_t n_global, int64_t row_begin, int64_t n_rows, const int32_t* rowptr,
                            const int32_t* col_global, const double* val, int es, int column_blocks, eigenex_csr_t* out) {
-  if (column_blocks < -2 || column_blocks > kMaxColumnBlocks) return fail(EIGENEX_ERR_ARG, "column_blocks must be in [-2, 16]");
+  if (column_blocks < -3 || column_blocks > kMaxColumnBlocks) return fail(EIGENEX_ERR_ARG, "column_blocks must be in [-3, 16]");
   if (!c || !out || !rowptr || n_global <= 0 || n_rows < 0) return fail(EIGENEX_ERR_ARG, "eigenex_csr_upload: bad argument");
   if (n_rows > 0 && rowptr[n_rows] > rowptr[0] && (!col_global || !val)) return fail(EIGENEX_ERR_ARG, "col/val is NULL");
   HIPCHK(hipSetDevice(c->device));
@@ -2158,6 +2204,7 @@ int eigenex_csr_layout(eigenex_csr_t m, int* layout) {
   *layout = EIGENEX_LAYOUT_CSR;
   for (auto& s : m->sh) {
     if (s.blocked) *layout = EIGENEX_LAYOUT_DENSE_BLOCKS;
+    else if (s.split) *layout = EIGENEX_LAYOUT_SPLIT_TILES;
     else if (s.sorted) *layout = EIGENEX_LAYOUT_SORTED_TILES;
     else if (s.passes > 1 && *layout == EIGENEX_LAYOUT_CSR) *layout = EIGENEX_LAYOUT_COLUMN_BLOCKED;
   }
@@ -2352,7 +2399,7 @@ int eigenex_basis_create_ex(eigenex_context_t c, eigenex_csr_t csr, int64_t n_gl
       HIPCHK(hipMalloc(&s.w, sizeof(double) * (size_t)(s.ldv + s.nhalo + 8) * s.es));
       HIPCHK(hipMemsetAsync(s.w, 0, sizeof(double) * (size_t)(s.ldv + s.nhalo + 8) * s.es, c->stream));
       s.g_vec = grid_for_tiles((s.nd + kTileRows - 1) / kTileRows, kDefaultVecBlocksPerCu);
-      s.g_spmv = (s.csr && s.csr->sorted) ? sorted_grid(s.nloc, s.csr->tile_rows) : grid_for_tiles((s.nloc + kSpmvRows - 1) / kSpmvRows, kDefaultSpmvBlocksPerCu);
+      s.g_spmv = (s.csr && s.csr->split) ? split_combine_grid(s.nloc) : (s.csr && s.csr->sorted) ? sorted_grid(s.nloc, s.csr->tile_rows) : grid_for_tiles((s.nloc + kSpmvRows - 1) / kSpmvRows, kDefaultSpmvBlocksPerCu);
       // room for eigenex_basis_tune up to kMaxBlocksPerCu workgroups per CU
       s.pstride = std::max(grid_for_tiles((s.nd + kTileRows - 1) / kTileRows, kMaxBlocksPerCu),
                            grid_for_tiles((s.nloc + kSpmvRows - 1) / kSpmvRows, kMaxBlocksPerCu));
@@ -2447,7 +2494,7 @@ int eigenex_basis_tune(eigenex_basis_t b, int vec_blocks_per_cu, int spmv_blocks
     return fail(EIGENEX_ERR_ARG, "eigenex_basis_tune: blocks per CU must be in [1, 16]");
   for (auto& s : b->sh) {
     s.g_vec = grid_for_tiles((s.nd + kTileRows - 1) / kTileRows, vec_blocks_per_cu);
-    s.g_spmv = (s.csr && s.csr->sorted) ? sorted_grid(s.nloc, s.csr->tile_rows) : grid_for_tiles((s.nloc + kSpmvRows - 1) / kSpmvRows, spmv_blocks_per_cu);
+    s.g_spmv = (s.csr && s.csr->split) ? split_combine_grid(s.nloc) : (s.csr && s.csr->sorted) ? sorted_grid(s.nloc, s.csr->tile_rows) : grid_for_tiles((s.nloc + kSpmvRows - 1) / kSpmvRows, spmv_blocks_per_cu);
     s.spmv_flags = flags & 3;  // bit 0: XCD-contiguous tiles, bit 1: non-temporal val/col loads
   }
   return 0;

@@ -192,14 +192,23 @@ int eigenex_csr_upload_z(eigenex_context_t ctx, int64_t n_global, int64_t row_be
  * useless for stencils.  Each row's running sum is carried from pass to pass, so the result is bit-identical to
  * the single-pass row loop whenever the slices are met in stored order along every row (always true for rows
  * with ascending columns); otherwise the entries of a row are added slice by slice (rounding-level difference).
- *   column_blocks = -1  automatic (what eigenex_csr_upload[_z] do): block only if the input vector exceeds L2,
- *                       rows are long enough, the gathers are scattered, and the result stays bit-identical
+ *   column_blocks = -1  automatic (what eigenex_csr_upload[_z] do): another layout than plain CSR only if the input vector
+ *                       exceeds L2, rows are long enough and the gathers are scattered; -3, -2 or blocked passes, in that
+ *                       order of preference (the last two only when the result stays bit-identical)
  *   column_blocks = 0,1 never;  2..16: that many passes, unconditionally
  *   column_blocks = -2  column-sorted row tiles (what the automatic mode prefers for real operators since round 2): the
  *                       entries of every (4096-row tile, 256 KB input slice) are stored sorted by column, so that the lanes
  *                       of a wave gather from shared 128-byte lines, with a 16-bit slot that restores the row order for
  *                       the sums; one launch, slices walked inside the kernel, bit-identical to the row loop.  Needs a
- *                       real operator with 2..64 slices whose rows meet the slices in stored order; error otherwise */
+ *                       real operator with 2..64 slices whose rows meet the slices in stored order; error otherwise
+ *   column_blocks = -3  split tiles (what the automatic mode takes, ahead of the column-sorted tiles, when a 16384-row tile
+ *                       has >= 3 gathers per 128-byte input line): one workgroup per (row tile, column group) adds
+ *                       column-sorted entries into partial row sums in LDS, a second kernel adds the <= 8 partial sums of a
+ *                       row in ascending group order.  The ONLY layout that re-associates a row's sum: y differs from the
+ *                       row loop by a few ulp of sum |a_ij x_j| (products are still rounded before they are added), the
+ *                       same bits on every run.  1.35x over the column-sorted tiles on BASELINE config 3.  Real operators;
+ *                       error if a row has thousands of entries in one column group.  Setting the environment variable
+ *                       EIGENEX_EXACT_ROW_SUMS keeps the automatic mode to the layouts that are bit-identical to the row loop */
 int eigenex_csr_upload_ex(eigenex_context_t ctx, int64_t n_global, int64_t row_begin, int64_t n_rows,
                           const int32_t* rowptr, const int32_t* col_global, const double* val, int is_complex,
                           int column_blocks, eigenex_csr_t* out);
@@ -226,8 +235,10 @@ int eigenex_csr_upload_device(eigenex_context_t ctx, int64_t n, const int32_t* r
                               const double* val_dev, int is_complex, eigenex_csr_t* out);
 /* passes of the (largest) local shard: 1 = not column-blocked */
 int eigenex_csr_column_blocks(eigenex_csr_t csr, int* passes);
-/* how the operator is stored on the device (the layout never changes a result when it was chosen automatically) */
-enum { EIGENEX_LAYOUT_CSR = 0, EIGENEX_LAYOUT_COLUMN_BLOCKED = 1, EIGENEX_LAYOUT_SORTED_TILES = 2, EIGENEX_LAYOUT_DENSE_BLOCKS = 3 };
+/* how the operator is stored on the device.  A layout chosen automatically never changes a result, with one exception:
+ * EIGENEX_LAYOUT_SPLIT_TILES adds a row's products in another association (see column_blocks = -3) */
+enum { EIGENEX_LAYOUT_CSR = 0, EIGENEX_LAYOUT_COLUMN_BLOCKED = 1, EIGENEX_LAYOUT_SORTED_TILES = 2, EIGENEX_LAYOUT_DENSE_BLOCKS = 3,
+       EIGENEX_LAYOUT_SPLIT_TILES = 4 };
 int eigenex_csr_layout(eigenex_csr_t csr, int* layout);
 /* synthetic 7-point Laplacian on an n^3 grid generated on the device (BASELINE configs 2 and 4) */
 int eigenex_csr_laplacian3d(eigenex_context_t ctx, int64_t n, eigenex_csr_t* out);

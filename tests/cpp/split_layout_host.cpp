@@ -1,0 +1,115 @@
+// CPU check of the split-tiles layout builder (csrc/split_layout.hpp), built with AddressSanitizer + UBSan by
+// tests/test_cabi_and_host_logic.py: replays what k_spmv_split + k_split_combine do with the layout on the host and compares
+// with the CSR row loop on integer-valued data (every association of the sums is exact), and checks the invariants the
+// kernel relies on: no row twice in a chunk, relative columns < 2^18, entry ranges aligned to 4 and inside the arrays, every
+// stored entry used exactly once, full 256-blocks transposed (the lanes of one gather instruction see ascending columns).
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "split_layout.hpp"
+
+using namespace eigenex;
+
+static int fail(const char* what, long a = 0, long b = 0) {
+  std::printf("FAIL: %s (%ld, %ld)\n", what, a, b);
+  return 1;
+}
+
+static int one_case(int64_t n, int top, int heavy, int heavy_len, int T, int G, int64_t n_low, unsigned seed) {
+  // columns live in "global order" positions 0 .. ext: n_low halo positions below, n own rows, some above
+  const int64_t ext = n + n_low + 37;
+  std::mt19937_64 rng(seed);
+  std::vector<int32_t> rp((size_t)n + 1, 0), col;
+  std::vector<double> val;
+  for (int64_t r = 0; r < n; ++r) {
+    int len = (int)(rng() % (uint64_t)top);
+    if (heavy && rng() % (uint64_t)(n / heavy + 1) == 0) len = heavy_len;
+    if (rng() % 50 == 0) len = 0;
+    std::vector<int32_t> c((size_t)len);
+    for (auto& x : c) x = (int32_t)(rng() % (uint64_t)ext);
+    std::sort(c.begin(), c.end());
+    for (int32_t x : c) col.push_back(x), val.push_back((double)((int)(rng() % 17) - 8));
+    rp[(size_t)r + 1] = (int32_t)col.size();
+  }
+  std::vector<double> x((size_t)ext);
+  for (auto& v : x) v = (double)((int)(rng() % 9) - 4);
+  auto ident = [](int64_t lc) { return lc; };
+  SplitLayout L;
+  if (!build_split_layout(n, ext, rp.data(), col.data(), val.data(), ident, T, G, L)) return fail("layout not built", n, T);
+  const int64_t ntiles = (n + T - 1) / T;
+  if (L.ntiles != ntiles || (int64_t)L.wg_chunk.size() != ntiles * G + 1) return fail("workgroup table", L.ntiles, (long)L.wg_chunk.size());
+  std::vector<double> y((size_t)n, 0.0), part((size_t)G * n, 0.0);
+  std::vector<int> seen((size_t)T, -1);
+  size_t used = 0;
+  int chunk_serial = 0;
+  for (int64_t wg = 0; wg < ntiles * G; ++wg) {
+    const int64_t tile = wg / G, g = wg % G;
+    std::vector<double> acc((size_t)T, 0.0);
+    if (L.wg_chunk[(size_t)wg] > L.wg_chunk[(size_t)wg + 1]) return fail("chunk ranges not ascending", wg);
+    for (int32_t c = L.wg_chunk[(size_t)wg]; c < L.wg_chunk[(size_t)wg + 1]; ++c, ++chunk_serial) {
+      const int32_t e0 = L.chunk[4 * (size_t)c], e1 = L.chunk[4 * (size_t)c + 1], pos0 = L.chunk[4 * (size_t)c + 2];
+      if ((e0 & 3) || e1 <= e0 || e1 - e0 > kSplitChunk || (size_t)e1 + 3 >= L.cp.size()) return fail("chunk range", e0, e1);
+      int64_t prev = -1;
+      for (int32_t q = e0; q < e1; ++q) {
+        const uint32_t cp = L.cp[(size_t)q];
+        const uint32_t rel = cp & ((1u << kSplitRelBits) - 1), row = cp >> kSplitRelBits;
+        if ((int)row >= T || tile * T + row >= n) return fail("row out of the tile", row, tile);
+        if (seen[row] == chunk_serial) return fail("a row twice in one chunk", row, c);
+        seen[row] = chunk_serial;
+        const int64_t pos = (int64_t)pos0 + rel;
+        if (pos < 0 || pos >= ext || pos / ((ext + G - 1) / G) != g) return fail("column outside its group", (long)pos, (long)g);
+        // within a full transposed block, storage index 4*lane + j holds sorted[64*j + lane]: ascending along lanes for fixed j
+        const int32_t off = q - e0, blk = off / 256, in = off % 256;
+        if ((int64_t)(blk + 1) * 256 <= e1 - e0 && in >= 4) {
+          const uint32_t left = L.cp[(size_t)q - 4] & ((1u << kSplitRelBits) - 1);
+          if (left > rel) return fail("lanes of one gather instruction not ascending", q, c);
+        }
+        (void)prev;
+        acc[row] += L.val[(size_t)q] * x[(size_t)pos];
+        ++used;
+      }
+    }
+    for (int64_t i = 0; i < T && tile * T + i < n; ++i) part[(size_t)g * n + tile * T + i] = acc[(size_t)i];
+  }
+  if (used != val.size()) return fail("entries used", (long)used, (long)val.size());
+  for (int64_t r = 0; r < n; ++r) {
+    double s = part[(size_t)r];
+    for (int g = 1; g < G; ++g) s += part[(size_t)g * n + r];
+    double ref = 0.0;
+    for (int32_t p = rp[(size_t)r]; p < rp[(size_t)r + 1]; ++p) ref += val[(size_t)p] * x[(size_t)col[(size_t)p]];
+    if (s != ref) return fail("row sum", (long)r);
+    y[(size_t)r] = s;
+  }
+  std::printf("ok: n=%ld T=%d G=%d chunks=%zu entries=%zu\n", (long)n, T, G, L.chunk.size() / 4 - 2, val.size());
+  return 0;
+}
+
+int main() {
+  int T = 0, G = 0;
+  if (!split_geometry(1000000, 240, 4096, &T, &G) || T != 16384 || G != 4) return fail("geometry of BASELINE config 3", T, G);
+  if (split_geometry(50000, 240, 4096, &T, &G)) return fail("a small shard must not get split tiles automatically", T, G);
+  if (!split_geometry(9001, 240, 256, &T, &G) || T != 256) return fail("forced geometry", T, G);
+  int rc = 0;
+  rc |= one_case(9001, 30, 5, 300, 256, 7, 0, 1);
+  rc |= one_case(70001, 25, 10, 200, 2048, 7, 1234, 2);
+  rc |= one_case(20000, 12, 0, 0, 16384, 8, 0, 3);       // one full tile and a partial one
+  rc |= one_case(5000, 40, 50, 60, 1024, 1, 77, 4);       // one group: the entries of a 60-entry row go to 60 different chunks
+  rc |= one_case(300, 3, 0, 0, 256, 8, 0, 5);             // nearly empty groups
+  {  // a dense row: one chunk per entry would be needed -> the builder refuses
+    const int64_t n = 3000;
+    std::vector<int32_t> rp((size_t)n + 1, 0), col;
+    std::vector<double> val;
+    for (int64_t r = 0; r < n; ++r) {
+      if (r == 17)
+        for (int32_t c = 0; c < n; ++c) col.push_back(c), val.push_back(1.0);
+      rp[(size_t)r + 1] = (int32_t)col.size();
+    }
+    SplitLayout L;
+    auto ident = [](int64_t lc) { return lc; };
+    if (build_split_layout(n, n, rp.data(), col.data(), val.data(), ident, 1024, 2, L)) rc |= fail("dense row accepted");
+  }
+  if (!rc) std::printf("SPLIT LAYOUT OK\n");
+  return rc;
+}

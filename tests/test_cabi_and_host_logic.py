@@ -292,3 +292,21 @@ def test_plain_c99_host_of_the_gpu_free_entry_points(built, tmp_path):
     out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert out.returncode == 0, (out.stdout + out.stderr).decode()[-2000:]
     assert b"c host: ok" in out.stdout
+
+
+def test_split_tiles_layout_builder_under_sanitizers(tmp_path):
+    """csrc/split_layout.hpp (the host-side builder of the split-tiles operator layout: sort by column, chunks without a
+    repeated row, deferred entries, transposed blocks) compiled with AddressSanitizer + UBSan; the test program replays
+    the two kernels on the host against the CSR row loop and checks the invariants the kernel relies on."""
+    import shutil
+    import subprocess
+
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    exe = str(tmp_path / "split_layout_host")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-pthread",
+                           "-I", os.path.join(ROOT, "cmpt-eigenex_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "cpp", "split_layout_host.cpp"), "-o", exe])
+    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0, (out.stdout.decode()[-1500:], out.stderr.decode()[-1500:])
+    assert b"SPLIT LAYOUT OK" in out.stdout

@@ -1,0 +1,193 @@
+"""Split tiles (k_spmv_split + k_split_combine, csrc/split_layout.hpp): the one operator layout that re-associates a row's
+sum -- partial sums per column group in LDS, added in ascending group order by a second kernel.  What is checked:
+
+* integer-valued data (every association of the sums is exact in fp64): bit-identical to the oracle's row loop, i.e. every
+  stored entry is used exactly once with the right row and column -- ragged rows, empty rows, duplicate columns, rows with
+  many entries in one group (deferred from chunk to chunk), many tiles and groups, partial last tile, 1 and 3 shards
+  (halo columns below and above the own rows);
+* real data: |y - row loop| <= 32 eps * sum_j |a_ij x_j| per row (products are rounded before they are added, n + G adds
+  in another order), the same bits on a second application (no unordered add), shift, the fused dot, the self-norm;
+* tiny products (denormal partial sums): the LDS adds neither flush nor round differently from numpy;
+* an Arnoldi run on the split layout against the plain CSR layout: Hessenberg entries within 1e-10 * |H|_max (north star
+  tolerance for Ritz values), and against the oracle;
+* the automatic choice: split tiles for a large scattered operator, bit-exact layouts with EIGENEX_EXACT_ROW_SUMS.
+The reference's operator is a user callback (lanczos.hpp:116, :389); the row loop is this library's plain-CSR definition of it."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+EPS = np.finfo(float).eps
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from cmpt_eigenex_amd import capi as m
+
+    assert m.device_count() >= 1
+    return m
+
+
+@pytest.fixture(scope="module")
+def cref():
+    from oracle import cref as m
+
+    return m
+
+
+def ragged(rng, n, top, heavy=0, heavy_len=0, integer=False):
+    counts = rng.integers(0, top, n)
+    counts[rng.integers(0, n, max(1, n // 50))] = 0
+    if heavy:
+        counts[rng.integers(0, n, heavy)] = heavy_len
+    rowptr = np.zeros(n + 1, np.int64)
+    np.cumsum(counts, out=rowptr[1:])
+    nnz = int(rowptr[-1])
+    col = rng.integers(0, n, nnz).astype(np.int64)
+    col = col[np.lexsort((col, np.repeat(np.arange(n), counts)))].astype(np.int32)
+    val = rng.integers(-8, 9, nnz).astype(float) if integer else rng.uniform(-1, 1, nnz)
+    return rowptr.astype(np.int32), col, val
+
+
+@pytest.mark.parametrize("shards", [1, 3])
+def test_split_tiles_use_every_entry_once(capi, cref, shards):
+    rng = np.random.default_rng(77 + shards)
+    # (rows, longest ordinary row, heavy rows, their length): 9,001 rows -> 256-row tiles x 7-8 groups; 70,001 -> 2048-row
+    # tiles; 300,000 -> 16384-row tiles, 8 groups; heavy rows put dozens of entries of one row into one group (one chunk each)
+    for n, top, heavy, hl in ((9_001, 30, 5, 120), (70_001, 25, 10, 200), (300_000, 12, 20, 120)):
+        rowptr, col, val = ragged(rng, n, top, heavy, hl, integer=True)
+        x = rng.integers(-4, 5, n).astype(float)
+        y_ref = cref.csr_spmv(rowptr, col, val, x, nthreads=4)
+        ctx = capi.Context(loopback_shards=shards) if shards > 1 else capi.Context()
+        A = capi.Csr.upload(ctx, n, rowptr, col, val, column_blocks=-3)
+        assert A.layout() == "split_tiles"
+        b = capi.Basis(ctx, A, n, 2)
+        b.upload(capi.VEC_W, x)
+        dot = b.apply(capi.VEC_W, capi.VEC_V, 0.0, want_dot=True)
+        np.testing.assert_array_equal(b.download(capi.VEC_V), y_ref)
+        assert dot == float(x @ y_ref)  # integers: exact
+        b.apply(capi.VEC_W, capi.VEC_V, 3.0)
+        np.testing.assert_array_equal(b.download(capi.VEC_V), y_ref + 3.0 * x)
+        b.close()
+        A.close()
+        ctx.close()
+
+
+@pytest.mark.parametrize("shards", [1, 2])
+def test_split_tiles_rounding_level_and_repeatable(capi, cref, shards):
+    rng = np.random.default_rng(5 + shards)
+    for n, top in ((40_000, 40), (250_000, 20)):
+        rowptr, col, val = ragged(rng, n, top, 8, 150)
+        x = rng.standard_normal(n)
+        y_ref = cref.csr_spmv(rowptr, col, val, x, nthreads=4)
+        mag = cref.csr_spmv(rowptr, col, np.abs(val), np.abs(x), nthreads=4)
+        ctx = capi.Context(loopback_shards=shards) if shards > 1 else capi.Context()
+        A = capi.Csr.upload(ctx, n, rowptr, col, val, column_blocks=-3)
+        b = capi.Basis(ctx, A, n, 2)
+        b.upload(capi.VEC_W, x)
+        dot = b.apply(capi.VEC_W, capi.VEC_V, 0.0, want_dot=True)
+        y = b.download(capi.VEC_V)
+        assert np.all(np.abs(y - y_ref) <= 32 * EPS * mag), float(np.max(np.abs(y - y_ref) / (mag + 1e-300)))
+        assert abs(dot - x @ y) <= 1e-13 * np.linalg.norm(x) * np.linalg.norm(y)
+        b.apply(capi.VEC_W, capi.VEC_V, 0.0)
+        np.testing.assert_array_equal(b.download(capi.VEC_V), y)  # same bits on every application
+        b.apply(capi.VEC_W, capi.VEC_V, -0.375)
+        np.testing.assert_array_equal(b.download(capi.VEC_V), y + (-0.375) * x)  # shift added unfused, like the row loop
+        b.close()
+        A.close()
+        ctx.close()
+
+
+def test_split_tiles_denormal_partial_sums(capi):
+    """two entries per row with products of 1e-310: the partial sums live in the denormal range"""
+    n = 5000
+    rng = np.random.default_rng(3)
+    rowptr = (2 * np.arange(n + 1)).astype(np.int32)
+    col = np.sort(rng.integers(0, n, (n, 2)), axis=1).astype(np.int32).ravel()
+    val = rng.uniform(1.0, 2.0, 2 * n)
+    x = np.full(n, 1e-310)
+    ctx = capi.Context()
+    A = capi.Csr.upload(ctx, n, rowptr, col, val, column_blocks=-3)
+    b = capi.Basis(ctx, A, n, 2)
+    b.upload(capi.VEC_W, x)
+    b.apply(capi.VEC_W, capi.VEC_V, 0.0)
+    y = b.download(capi.VEC_V)
+    p = (val * x[col]).reshape(n, 2)
+    np.testing.assert_array_equal(y, p[:, 0] + p[:, 1])  # two terms: one association only
+    assert np.all(y > 0) and np.all(y < 1e-300)
+    ctx.close()
+
+
+def test_split_tiles_arnoldi_against_csr_layout_and_oracle(capi, cref):
+    n, per, m = 150_000, 16, 30
+    rng = np.random.default_rng(12)
+    col = np.sort(rng.integers(0, n, (n, per)), axis=1).astype(np.int32).ravel()
+    rowptr = (per * np.arange(n + 1)).astype(np.int32)
+    val = rng.uniform(-1, 1, n * per)
+    start = rng.standard_normal(n)
+    ctx = capi.Context()
+    H = {}
+    for K in (-3, 0):
+        A = capi.Csr.upload(ctx, n, rowptr, col, val, column_blocks=K)
+        b = capi.Basis(ctx, A, n, m)
+        b.configure(ortho_mode=capi.ORTHO_BATCHED_ADAPTIVE)
+        b.upload(capi.VEC_W, start)
+        b.arnoldi_enqueue(m)
+        st, h = b.arnoldi_state()
+        assert (st.nvec, st.stopped) == (m, 0)
+        H[K] = h.copy()
+        b.close()
+        A.close()
+    scale = np.abs(H[0]).max()
+    assert np.abs(H[-3] - H[0]).max() <= 1e-10 * scale
+    assert np.abs(H[-3] - H[0]).max() > 0  # it IS another association
+    c = cref.CArnoldi(rowptr, col, val, start, cap=m + 1)
+    assert c.run(m) == m
+    Href = c.hessenberg()
+    k = min(Href.shape[0], H[-3].shape[0])
+    assert np.abs(H[-3][:k, :k] - Href[:k, :k]).max() <= 1e-10 * scale
+    ev, evr = np.linalg.eigvals(H[-3][:k, :k]), np.linalg.eigvals(Href[:k, :k])
+    top, topr = ev[np.argsort(-np.abs(ev))[:4]], evr[np.argsort(-np.abs(evr))[:4]]
+    assert np.abs(np.sort_complex(top) - np.sort_complex(topr)).max() <= 1e-10 * np.abs(topr).max()
+    ctx.close()
+
+
+def test_automatic_choice_and_exact_row_sums_switch(capi):
+    """a 600,000-row operator with 24 scattered entries per row: 16384-row tiles have 10 gathers per input line -> split tiles;
+    with EIGENEX_EXACT_ROW_SUMS in the environment the automatic mode stays with a layout that is bit-identical to the row
+    loop (checked in a child process: the library reads the variable once)"""
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, '.')
+from cmpt_eigenex_amd import capi
+from oracle import cref
+n, per = 600_000, 24
+rng = np.random.default_rng(1)
+col = np.sort(rng.integers(0, n, (n, per)), axis=1).astype(np.int32).ravel()
+rowptr = (per * np.arange(n + 1)).astype(np.int32)
+val = rng.uniform(-1, 1, n * per)
+x = rng.standard_normal(n)
+ctx = capi.Context()
+A = capi.Csr.upload(ctx, n, rowptr, col, val)
+b = capi.Basis(ctx, A, n, 2)
+b.upload(capi.VEC_W, x)
+b.apply(capi.VEC_W, capi.VEC_V, 0.0)
+y = b.download(capi.VEC_V)
+y_ref = cref.csr_spmv(rowptr, col, val, x, nthreads=4)
+print(A.layout(), int(np.count_nonzero(y != y_ref)), float(np.abs(y - y_ref).max()))
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for exact in (False, True):
+        env = dict(os.environ)
+        env.pop("EIGENEX_EXACT_ROW_SUMS", None)
+        if exact:
+            env["EIGENEX_EXACT_ROW_SUMS"] = "1"
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[exact] = r.stdout.split()[-3:]
+    assert out[False][0] == "split_tiles" and float(out[False][2]) < 1e-13
+    assert out[True][0] in ("sorted_tiles", "column_blocked", "csr") and int(out[True][1]) == 0
