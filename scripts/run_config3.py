@@ -49,6 +49,7 @@ def solve():
 
 
 solve()  # warm-up
+rate_plain = None
 if "--no-profile" in sys.argv:  # what a user gets: no per-launch events, recorded batches replayed
     for _ in range(2):
         solve()
@@ -58,6 +59,7 @@ if "--no-profile" in sys.argv:  # what a user gets: no per-launch events, record
         st, H = solve()
     ctx.sync()
     dt = (time.perf_counter() - t0) / solves
+    rate_plain = m / dt
     print(f"without per-launch events: {m / dt:.1f} it/s ({dt * 1e3:.2f} ms per solve)", flush=True)
 ctx.profile_reset()
 ctx.profile_enable(True)
@@ -83,7 +85,8 @@ spmv_ms_per_app = prof["spmv"]["ms"] / napp
 print(f"operator: {spmv_ms_per_app * 1e3:.1f} us per application = {op_bytes / spmv_ms_per_app / 1e6:.0f} GB/s algorithmic "
       f"({op_bytes / spmv_ms_per_app / 1e6 / 8000:.3f} of 8 TB/s)")
 if out_json:
-    json.dump(dict(N=N, nnz=nnz, m=m, passes=A.column_blocks(), it_per_s=m / dt, ms_per_solve=dt * 1e3,
+    json.dump(dict(N=N, nnz=nnz, m=m, layout=A.layout(), passes=A.column_blocks(), it_per_s_without_events=rate_plain,
+                   it_per_s=m / dt, ms_per_solve=dt * 1e3,
                    spmv_us_per_application=spmv_ms_per_app * 1e3, spmv_algorithmic_gbs=op_bytes / spmv_ms_per_app / 1e6,
                    kernels=prof), open(out_json, "w"), indent=1)
 print("OK")
