@@ -65,7 +65,12 @@ def test_lanczos_front_end_fuzz(mods, seed):
     ref.compute()
 
     ctx = capi.Context(loopback_shards=shards) if shards > 1 else capi.Context()
-    op = capi.Csr.upload(ctx, n, A.indptr, A.indices, A.data)
+    # operator layout (its own generator: the cases above stay what they were): automatic, plain CSR, split tiles (row sums
+    # re-associated at rounding level), three column-blocked passes
+    layout = [None, None, 0, -3, 3][int(np.random.default_rng(70000 + seed).integers(5))]
+    if np.iscomplexobj(A.data) and layout == -3:
+        layout = None
+    op = capi.Csr.upload(ctx, n, A.indptr, A.indices, A.data, column_blocks=layout)
     es = solver.LanczosEigenSolver()
     es.setDeviceOperator(op).set(minIterations=settings["min_iterations"], maxIterations=settings["max_iterations"],
                                  tolerance=settings["tolerance"], indicesForConvergence=settings["indices_for_convergence"],
@@ -146,7 +151,8 @@ def test_arnoldi_front_end_fuzz(mods, seed):
         setattr(ref, k, v)
     ref.compute()
     ctx = capi.Context(loopback_shards=shards) if shards > 1 else capi.Context()
-    op = capi.Csr.upload(ctx, n, A.indptr, A.indices, A.data)
+    layout = [None, None, 0, -3, 3][int(np.random.default_rng(90000 + seed).integers(5))]
+    op = capi.Csr.upload(ctx, n, A.indptr, A.indices, A.data, column_blocks=layout)
     es = solver.ArnoldiEigenSolver()
     es.setDeviceOperator(op).set(minIterations=settings["min_iterations"], maxIterations=m, maxEigenvalues=settings["max_eigenvalues"],
                                  computeEigenvectorsOn=int(settings["compute_eigenvectors_on"]), eigenvalueShift=shift, initialVector=init)
