@@ -1625,14 +1625,19 @@ void launch_spmv_sorted(hipStream_t s, const SortedOperatorView& op, const doubl
 
 int split_combine_grid(int64_t n) { return grid_for_tiles((n + 2 * kBlock - 1) / (2 * kBlock), 8); }
 
+// gathers one chunk ahead, LDS atomics (ds_add_f64, nothing returned): measured 121 us on BASELINE config 3 against 125 / 123 us
+// two / three chunks ahead and 126-130 us with read-add-write (scripts/microbench/split_tiles.hip)
+static const auto k_spmv_split_used = k_spmv_split<1>;
+bool prepare_spmv_split() {  // the kernel needs up to 128 KB of dynamic LDS: allowed once, at upload (not inside a stream capture)
+  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmv_split_used), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)(sizeof(double) * kSplitMaxTileRows)) == hipSuccess;
+  return ok;
+}
+
 void launch_spmv_split(hipStream_t s, const SplitOperatorView& op, const double* x_ext, const double* scale, double shift, double* y,
                        double* u_out, int64_t n, double* partials, const Ctrl* ctrl, int pass) {
-  // gathers one chunk ahead, LDS atomics (ds_add_f64, nothing returned): measured 121 us on BASELINE config 3 against 125 / 123 us
-  // two / three chunks ahead and 126-130 us with read-add-write (scripts/microbench/split_tiles.hip)
-  static const auto kernel = k_spmv_split<1>;
-  static const bool attr_set = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                   (int)(sizeof(double) * kSplitMaxTileRows)) == hipSuccess;
-  (void)attr_set;
+  const auto kernel = k_spmv_split_used;
+  (void)prepare_spmv_split();
   const int64_t ntiles = (n + op.tile_rows - 1) / op.tile_rows;
   hipLaunchKernelGGL(kernel, dim3((unsigned)(ntiles * op.groups)), dim3(kSplitBlock), sizeof(double) * op.tile_rows, s, op, x_ext,
                      scale, ctrl);

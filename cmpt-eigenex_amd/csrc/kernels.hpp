@@ -132,6 +132,7 @@ struct SplitOperatorView {
   int64_t part_stride;
 };
 int split_combine_grid(int64_t n);
+bool prepare_spmv_split();
 void launch_spmv_split(hipStream_t s, const SplitOperatorView& op, const double* x_ext, const double* scale, double shift, double* y,
                        double* u_out, int64_t n, double* partials, const Ctrl* ctrl, int pass = 0);
 // Block-sparse operator (the reference's BlockTensor<Scalar,2> layout, block_tensor.hpp:1193-1206, real or complex fp64):

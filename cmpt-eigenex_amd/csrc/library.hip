@@ -627,9 +627,22 @@ bool build_sorted_layout_t(const CsrShard& s, const std::vector<int32_t>& lcol, 
     }
   };
   {
+    auto guarded = [&](int th) {  // an exception (std::bad_alloc) must not leave a worker thread
+      try {
+        work(th);
+      } catch (...) {
+        pieces[(size_t)th].ok = false;
+      }
+    };
     std::vector<std::thread> pool;
-    for (int th = 1; th < nthreads; ++th) pool.emplace_back(work, th);
-    work(0);
+    for (int th = 1; th < nthreads; ++th) {
+      try {
+        pool.emplace_back(guarded, th);
+      } catch (...) {  // no more threads to be had: do the piece here
+        guarded(th);
+      }
+    }
+    guarded(0);
     for (auto& t : pool) t.join();
   }
   size_t total = 8;
@@ -718,6 +731,7 @@ int build_shard_host(eigenex_context_s* c, int64_t n_global, int gshard, const i
     SplitLayout L;
     const GlobalOrder order(s);
     if (want && build_split_layout(s.nloc, s.nloc + s.nhalo, lrp.data(), lcol.data(), vsrc, order, T, G, L)) {
+      if (!prepare_spmv_split()) return fail(EIGENEX_ERR_HIP, "k_spmv_split: 128 KB of dynamic LDS refused");
       s.split = true;
       s.sp_groups = L.G;
       s.tile_rows = L.T;

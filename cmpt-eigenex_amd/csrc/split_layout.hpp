@@ -158,9 +158,22 @@ bool build_split_layout(int64_t nloc, int64_t ext, const int32_t* lrp, const int
     }
   };
   {
+    auto guarded = [&](int th) {  // an exception (std::bad_alloc) must not leave a worker thread
+      try {
+        work(th);
+      } catch (...) {
+        pieces[(size_t)th].ok = false;
+      }
+    };
     std::vector<std::thread> pool;
-    for (int th = 1; th < nthreads; ++th) pool.emplace_back(work, th);
-    work(0);
+    for (int th = 1; th < nthreads; ++th) {
+      try {
+        pool.emplace_back(guarded, th);
+      } catch (...) {  // no more threads to be had: do the piece here
+        guarded(th);
+      }
+    }
+    guarded(0);
     for (auto& t : pool) t.join();
   }
   size_t total = 8, nchunks = 0;
