@@ -1,4 +1,4 @@
-// COO ("triplets") ingestion for the device operator, and the Gershgorin range helper.
+// COO ("triplets") and compressed-sparse-column ingestion for the device operator, and the Gershgorin range helper.
 //
 // The reference's only in-tree sparse operator is COO: TripletsMatrix::operate zero-fills and
 // scatter-adds in triplet order (triplets_matrix.hpp:314-329) and makeMatMulFunction() wraps it for
@@ -81,8 +81,63 @@ std::array<double, 2> estimateEigenvalueRange(Index n, Index count, const Index*
   }
   return std::array<double, 2>{{lo, hi}};
 }
+// Compressed sparse COLUMN arrays -> CSR rows [row_begin, row_end) with ascending columns.  This is the storage of the operator
+// in the reference's practical example: a default (column-major) Eigen::SparseMatrix, whose outerIndexPtr() / innerIndexPtr() /
+// valuePtr() of the compressed matrix are exactly (colptr, rowidx, val) (src/samples/sample_lanczos2.cpp:27-34).  Eigen's
+// H*v for such a matrix adds H(i,j)*v(j) into out(i) column after column, i.e. with j ascending and every product rounded
+// before it is added -- the order of the CSR row loop over ascending columns, which is what the device kernels reproduce.
+// Row indices inside a column need not be sorted; a repeated (i, j) stays two stored entries in their stored order.
+template <class Scalar, class StorageIndex>
+HostCsr<Scalar> csc_to_csr(Index n_rows, Index n_cols, const StorageIndex* colptr, const StorageIndex* rowidx, const Scalar* val,
+                           Index row_begin = 0, Index row_end = -1) {
+  if (row_end < 0) row_end = n_rows;
+  if (n_rows < 0 || n_cols < 0 || row_begin < 0 || row_end < row_begin || row_end > n_rows) throw LanczosException("csc_to_csr: bad row range");
+  HostCsr<Scalar> m;
+  m.n = n_rows;
+  m.rowptr.assign(static_cast<std::size_t>(row_end - row_begin) + 1, 0);
+  for (Index j = 0; j < n_cols; ++j) {
+    if (colptr[j + 1] < colptr[j]) throw LanczosException("csc_to_csr: column pointers must not decrease");
+    for (Index p = colptr[j]; p < colptr[j + 1]; ++p) {
+      const Index i = rowidx[p];
+      if (i < 0 || i >= n_rows) throw LanczosException("csc_to_csr: row index out of range");
+      if (i >= row_begin && i < row_end) m.rowptr[static_cast<std::size_t>(i - row_begin) + 1]++;
+    }
+  }
+  std::partial_sum(m.rowptr.begin(), m.rowptr.end(), m.rowptr.begin());
+  if (m.rowptr.back() < 0) throw LanczosException("csc_to_csr: more than 2^31 entries in one shard");
+  m.col.resize(static_cast<std::size_t>(m.rowptr.back()));
+  m.val.resize(static_cast<std::size_t>(m.rowptr.back()));
+  std::vector<std::int32_t> next(m.rowptr.begin(), m.rowptr.end() - 1);
+  for (Index j = 0; j < n_cols; ++j)  // columns ascending: every row receives its entries in ascending column order
+    for (Index p = colptr[j]; p < colptr[j + 1]; ++p) {
+      const Index i = rowidx[p];
+      if (i < row_begin || i >= row_end) continue;
+      const std::size_t q = static_cast<std::size_t>(next[static_cast<std::size_t>(i - row_begin)]++);
+      m.col[q] = static_cast<std::int32_t>(j);
+      m.val[q] = val[p];
+    }
+  return m;
+}
 
 namespace device {
+
+// device operator from a column-major sparse matrix (see csc_to_csr); every rank passes the whole matrix and keeps its rows
+template <class StorageIndex>
+inline std::shared_ptr<CsrOperator> csrFromCsc(std::shared_ptr<Context> ctx, Index n, const StorageIndex* colptr,
+                                               const StorageIndex* rowidx, const double* val) {
+  std::int64_t rb = 0, re = n;
+  if (ctx->shardsLocal() != ctx->shardsTotal()) check(eigenex_partition(n, ctx->worldSize(), ctx->rank(), &rb, &re), "eigenex_partition");
+  const HostCsr<double> m = csc_to_csr<double, StorageIndex>(n, n, colptr, rowidx, val, rb, re);
+  return std::make_shared<CsrOperator>(ctx, n, rb, re - rb, m.rowptr.data(), m.col.data(), m.val.data());
+}
+template <class StorageIndex>
+inline std::shared_ptr<CsrOperator> csrFromCsc(std::shared_ptr<Context> ctx, Index n, const StorageIndex* colptr,
+                                               const StorageIndex* rowidx, const std::complex<double>* val) {
+  std::int64_t rb = 0, re = n;
+  if (ctx->shardsLocal() != ctx->shardsTotal()) check(eigenex_partition(n, ctx->worldSize(), ctx->rank(), &rb, &re), "eigenex_partition");
+  const HostCsr<std::complex<double>> m = csc_to_csr<std::complex<double>, StorageIndex>(n, n, colptr, rowidx, val, rb, re);
+  return CsrOperator::complexCsr(ctx, n, rb, re - rb, m.rowptr.data(), m.col.data(), m.val.data());
+}
 
 // device operator from triplets; every rank passes the full list and keeps the rows of its shard
 inline std::shared_ptr<CsrOperator> csrFromTriplets(std::shared_ptr<Context> ctx, Index n, Index count, const Index* rows,

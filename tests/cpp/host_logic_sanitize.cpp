@@ -128,6 +128,38 @@ int main() {
     const auto empty = triplets_to_csr<double>(4, 0, nullptr, nullptr, nullptr);
     EXPECT(empty.rowptr.size() == 5 && empty.col.empty());
   }
+  // compressed-sparse-column ingestion (Eigen::SparseMatrix's default storage): the row loop over the produced CSR adds a
+  // row's products in the order in which the column-major product adds them (columns ascending) -> identical bits
+  {
+    const Index n = 37;
+    std::vector<int> colptr(1, 0), rowidx;
+    std::vector<double> cv, x(n), y_csc(n, 0.0), y_csr(n, 0.0);
+    std::uniform_int_distribution<int> cnt(0, 9), pick(0, (int)n - 1);
+    for (Index j = 0; j < n; ++j) {
+      const int k = cnt(rng);
+      for (int t = 0; t < k; ++t) rowidx.push_back(pick(rng)), cv.push_back(u(rng));  // unsorted rows, repeats allowed
+      colptr.push_back((int)rowidx.size());
+    }
+    for (auto& v : x) v = u(rng);
+    for (Index j = 0; j < n; ++j)  // what a column-major sparse product does
+      for (int p = colptr[j]; p < colptr[j + 1]; ++p) y_csc[rowidx[p]] += cv[p] * x[j];
+    const auto m = csc_to_csr<double, int>(n, n, colptr.data(), rowidx.data(), cv.data());
+    EXPECT(m.rowptr.back() == (std::int32_t)cv.size());
+    for (Index i = 0; i < n; ++i)
+      for (std::int32_t p = m.rowptr[i]; p < m.rowptr[i + 1]; ++p) {
+        EXPECT(p == m.rowptr[i] || m.col[p - 1] <= m.col[p]);
+        y_csr[i] += m.val[p] * x[m.col[p]];
+      }
+    for (Index i = 0; i < n; ++i) EXPECT(y_csr[i] == y_csc[i]);
+    const auto part = csc_to_csr<double, int>(n, n, colptr.data(), rowidx.data(), cv.data(), 9, 20);
+    EXPECT(part.rowptr.size() == 12 && part.rowptr.back() == m.rowptr[20] - m.rowptr[9]);
+    for (std::int32_t p = 0; p < part.rowptr.back(); ++p) EXPECT(part.col[p] == m.col[m.rowptr[9] + p] && part.val[p] == m.val[m.rowptr[9] + p]);
+    rowidx[3] = (int)n;
+    EXPECT(throws([&] { csc_to_csr<double, int>(n, n, colptr.data(), rowidx.data(), cv.data()); }));
+    rowidx[3] = 0;
+    colptr[5] = colptr[4] - 1 < 0 ? 0 : colptr[4] - 1;
+    if (colptr[5] < colptr[4]) EXPECT(throws([&] { csc_to_csr<double, int>(n, n, colptr.data(), rowidx.data(), cv.data()); }));
+  }
   // block description: ragged and empty sectors, accumulation, shape errors, row windows
   {
     BlockSparseMatrix<double> H({3, 0, 5, 1}, {2, 6, 0, 1});

@@ -10,6 +10,7 @@
 
 #include "cmpt/eigen_ex/arnoldi.hpp"
 #include "cmpt/eigen_ex/lanczos.hpp"
+#include "cmpt/eigen_ex/triplets_operator.hpp"
 
 int main() {
   using Scalar = std::complex<double>;
@@ -27,7 +28,7 @@ int main() {
   };
   try {
     std::printf("{");
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < 3; ++pass) {
       std::mt19937 random_engine(1);
       Solver es;
       std::shared_ptr<cmpt::EigenEx::device::Context> ctx;
@@ -43,7 +44,20 @@ int main() {
           rowptr.push_back((std::int32_t)col.size());
         }
         ctx = std::make_shared<cmpt::EigenEx::device::Context>(0);
-        op = cmpt::EigenEx::device::CsrOperator::complexCsr(ctx, n, 0, n, rowptr.data(), col.data(), val.data());
+        if (pass == 1) {
+          op = cmpt::EigenEx::device::CsrOperator::complexCsr(ctx, n, 0, n, rowptr.data(), col.data(), val.data());
+        } else {
+          // the sample's own storage: a column-major Eigen::SparseMatrix filled from the triplets (i, i+1, -i), (i+1, i, +i)
+          // (sample_lanczos2.cpp:20-28) -- outerIndexPtr / innerIndexPtr / valuePtr of the compressed matrix are these arrays
+          std::vector<int> colptr(1, 0), rowidx;
+          std::vector<Scalar> cval;
+          for (int j = 0; j < n; ++j) {
+            if (j > 0) { rowidx.push_back(j - 1); cval.push_back(Scalar(0.0, -1.0)); }   // H(j-1, j)
+            if (j + 1 < n) { rowidx.push_back(j + 1); cval.push_back(Scalar(0.0, 1.0)); }  // H(j+1, j)
+            colptr.push_back((int)rowidx.size());
+          }
+          op = cmpt::EigenEx::device::csrFromCsc<int>(ctx, n, colptr.data(), rowidx.data(), cval.data());
+        }
         es.setDeviceOperator(op);
       }
       es.setEigenvalueShift(0.0);
@@ -60,7 +74,7 @@ int main() {
       es.setReserveSize(128);
       es.compute();
       std::printf("%s\"%s\": {\"matrix_height\": %ld, \"iterations\": %ld, \"subspace_rank\": %ld, \"eigenvalues\": [",
-                  pass ? ", " : "", pass ? "device_operator" : "host_operator", (long)es.matrixHeight(), (long)es.iterations(),
+                  pass ? ", " : "", pass == 0 ? "host_operator" : (pass == 1 ? "device_operator" : "device_operator_from_csc"), (long)es.matrixHeight(), (long)es.iterations(),
                   (long)es.lanczosvectors().size());
       for (Index i = 0; i < es.eigenvalues().size(); ++i) std::printf("%s%.17g", i ? ", " : "", es.eigenvalues()[i]);
       // residual of the lowest pair, phase of its first entry

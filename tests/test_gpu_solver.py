@@ -487,7 +487,7 @@ def test_cpp_program_reference_sample_lanczos2_complex(golden_dir, tmp_path):
                            "-leigenex_hip", "-Wl,-rpath," + lib])
     out = json.loads(subprocess.check_output([exe]).decode())
     gold = json.load(open(os.path.join(golden_dir, "reference_samples.json")))["sample_lanczos2"]
-    for key in ("host_operator", "device_operator"):
+    for key in ("host_operator", "device_operator", "device_operator_from_csc"):
         o = out[key]
         assert o["matrix_height"] == 200 and len(o["eigenvalues"]) == 10 and o["hasWARN"] == 0
         assert o["subspace_rank"] == o["iterations"] + 1
@@ -497,6 +497,9 @@ def test_cpp_program_reference_sample_lanczos2_complex(golden_dir, tmp_path):
         assert o["log"][-2] == "INFO      lanczos steps converged with tolerance"
     assert out["host_operator"]["iterations"] == out["device_operator"]["iterations"]
     np.testing.assert_allclose(out["host_operator"]["eigenvalues"], out["device_operator"]["eigenvalues"], rtol=0, atol=1e-10)
+    # the sample's own operator storage (column-major sparse arrays) through device::csrFromCsc: the same CSR rows, so the
+    # same run bit for bit
+    assert out["device_operator_from_csc"] == out["device_operator"]
 
 
 def test_cpp_program_block_operator(tmp_path):
