@@ -971,7 +971,18 @@ __global__ __launch_bounds__(kBlock) void k_block_spmv(BlockOperatorView op, con
 #pragma unroll
       for (int t = 0; t < 8; ++t) sum = add_product_nofma(sum, a[t], xv[t]);
     }
-    for (; j < width; ++j) sum = add_product_nofma(sum, v[(int64_t)j * nr], x_ext[cl[j]] * scale);
+    if (j < width) {  // the last 1..7 columns: their loads in flight together, like a full batch (a serial tail loop cost 3 % at
+                      // strip width 30 -- BASELINE config 5's 10-row sectors -- and 8 % at width 6)
+      const int m = width - j;
+      double a[7], xv[7];
+#pragma unroll
+      for (int t = 0; t < 7; ++t) a[t] = t < m ? v[(int64_t)(j + t) * nr] : 0.0;
+#pragma unroll
+      for (int t = 0; t < 7; ++t) xv[t] = t < m ? x_ext[cl[j + t]] * scale : 0.0;
+#pragma unroll
+      for (int t = 0; t < 7; ++t)
+        if (t < m) sum = add_product_nofma(sum, a[t], xv[t]);
+    }
     const double xr = x_ext[r] * scale;
     double yr = sum;
     if (shift != 0.0) yr = add_product_nofma(yr, shift, xr);  // lanczos.hpp:390-392

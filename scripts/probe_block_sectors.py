@@ -30,7 +30,7 @@ y = bs.download(capi.VEC_V)
 print(json.dumps(dict(b=b, N=H.N, nnz=H.nnz, fmt=fmt, layout=A.layout(), us=ms / n * 1e3, checksum=float(np.abs(y).sum()), y0=float(y[H.N // 2]))))
 '''
 rows = []
-for b in (1, 2, 4, 8, 10, 16, 32):
+for b in [int(v) for v in os.environ.get("BLOCK_PROBE_B", "1,2,4,8,10,16,32").split(",")]:
     N = ENTRIES // (3 * b)
     N -= N % b
     res = {}
