@@ -986,6 +986,87 @@ ColumnSet colset(BasisShard& s, int first, int stride, int count, int qfirst, in
   return cs;
 }
 
+// Placement of the work vector that k_update writes in every step.  Measured (tests/probes/probe_update_placement.py,
+// scripts/microbench/placement.hip): with everything else equal -- same process, same virtual addresses, same slab -- the pass
+// "read j columns of 1 GB, write one vector" runs at 5.3 or at 6.0 TB/s depending only on WHICH PHYSICAL FRAMES the written
+// gigabyte got (k_update at 512^3: 9.16 or 9.67 ms per launch, alternating from one allocation to the next; k_dots, which writes
+// nothing, does not move).  This was the unexplained 5 % spread of the headline figure between processes and boxes.  So for
+// large vectors a few candidates are allocated (all held, so they are different frames), the very kernel is timed on each
+// over the first columns of the slab, the fastest is kept and the others are freed: about 40 ms once per Krylov state at
+// 512^3.  Pure placement: no result depends on it.  EIGENEX_NO_PLACEMENT_PROBE=1 keeps the first allocation.
+constexpr int64_t kPlacementMinDoubles = (int64_t)1 << 25;  // vectors of >= 256 MB
+constexpr int kPlacementCandidates = 6;
+int place_work_vector(eigenex_context_s* c, BasisShard& s, int capacity) {
+  static const bool off = std::getenv("EIGENEX_NO_PLACEMENT_PROBE") != nullptr;
+  if (off || s.nd < kPlacementMinDoubles || capacity < 2) return 0;
+  const size_t wbytes = sizeof(double) * (size_t)(s.ldv + s.nhalo + 8) * s.es;
+  const int ncols = std::min(capacity, 16);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  HIPCHK(hipEventCreate(&e0));
+  if (hipEventCreate(&e1) != hipSuccess) {
+    (void)hipEventDestroy(e0);
+    return fail(EIGENEX_ERR_HIP, "hipEventCreate");
+  }
+  auto probe = [&](double* cand, float* best) -> hipError_t {
+    *best = 1e30f;
+    for (int rep = 0; rep < 2; ++rep) {
+      hipError_t e = hipEventRecord(e0, c->stream);
+      if (e != hipSuccess) return e;
+      launch_update(c->stream, s.start, cand, ThreeTerm{nullptr, nullptr, nullptr, nullptr}, colset(s, 0, 1, ncols, 0, 0), s.hbuf, s.nd, s.partials,
+                    s.g_vec, s.ctrl_zero, s.es == 2);
+      if ((e = hipEventRecord(e1, c->stream)) != hipSuccess) return e;
+      if ((e = hipEventSynchronize(e1)) != hipSuccess) return e;
+      float ms = 0.f;
+      if ((e = hipEventElapsedTime(&ms, e0, e1)) != hipSuccess) return e;
+      *best = std::min(*best, ms);
+    }
+    return hipSuccess;
+  };
+  // candidates: the two vectors already there (w, and v -- the operator's output, written in every step as well) and up to
+  // kPlacementCandidates - 2 new ones of w's size; the fastest becomes w, the second fastest v
+  std::vector<std::pair<float, double*>> cand;
+  hipError_t err = hipSuccess;
+  for (double* p0 : {s.w, s.v}) {
+    float ms = 0.f;
+    if ((err = probe(p0, &ms)) != hipSuccess) break;
+    cand.push_back({ms, p0});
+  }
+  // v was allocated with the slab's column size; as a candidate for w it must be as large as w
+  const bool v_fits_w = sizeof(double) * (size_t)s.ldd >= wbytes;
+  for (int k = 2; k < kPlacementCandidates && err == hipSuccess; ++k) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < wbytes + ((size_t)2 << 30)) break;  // never the last gigabytes
+    double* p1 = nullptr;
+    if (hipMalloc(&p1, wbytes) != hipSuccess) {
+      (void)hipGetLastError();
+      break;
+    }
+    float ms = 0.f;
+    if ((err = hipMemsetAsync(p1, 0, wbytes, c->stream)) != hipSuccess || (err = probe(p1, &ms)) != hipSuccess) {
+      (void)hipFree(p1);
+      break;
+    }
+    cand.push_back({ms, p1});
+  }
+  if (err == hipSuccess && cand.size() >= 2) {
+    if (std::getenv("EIGENEX_DEBUG_POINTERS"))
+      for (auto& cd : cand) std::fprintf(stderr, "eigenex: placement candidate %p: %.3f ms\n", (void*)cd.second, cd.first);
+    std::stable_sort(cand.begin(), cand.end(), [](const std::pair<float, double*>& x, const std::pair<float, double*>& y) { return x.first < y.first; });
+    double* old_v = s.v;
+    size_t iw = 0;
+    if (cand[0].second == old_v && !v_fits_w) iw = 1;  // (halo slots make w larger than v: v's own buffer cannot become w)
+    s.w = cand[iw].second;
+    size_t iv = iw == 0 ? 1 : 0;
+    s.v = cand[iv].second;
+    for (size_t i = 0; i < cand.size(); ++i)
+      if (i != iw && i != iv) (void)hipFree(cand[i].second);
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (err != hipSuccess) return fail(EIGENEX_ERR_HIP, std::string("placement probe: ") + hipGetErrorString(err));
+  return 0;
+}
+
 // ---- enqueue helpers (all local shards, then the collective) -----------------
 // h[slot .. slot+ncols) = all-reduced dots of w0(src, tt) with the column set
 // use_ctrl: 0 = the always-zero control block (stand-alone primitives), 1 = the state's control block,
@@ -2436,6 +2517,7 @@ int eigenex_basis_create_ex(eigenex_context_t c, eigenex_csr_t csr, int64_t n_gl
       HIPCHK(hipMalloc(&s.ctrl_pass2, sizeof(Ctrl)));
       HIPCHK(hipMemsetAsync(s.ctrl_pass2, 0, sizeof(Ctrl), c->stream));
     }
+    for (auto& s : b->sh) CHK(place_work_vector(c, s, capacity));
     if (std::getenv("EIGENEX_DEBUG_POINTERS"))  // allocation placement, for timing investigations
       for (auto& s : b->sh)
         std::fprintf(stderr, "eigenex: shard %d V=%p (stride %lld B) v=%p w=%p start=%p partials=%p\n", s.gshard, (void*)s.V,
