@@ -68,6 +68,22 @@ int main(int argc, char** argv) {
     }
     for (int k = 0; k < nheld; ++k) CHK(hipFree(held[k]));
   }
+  {  // physically contiguous frames for the written vector (hipExtMallocWithFlags, hipDeviceMallocContiguous)
+    double2* held[8];
+    int nheld = 0;
+    for (int k = 0; k < 8; ++k) {
+      held[nheld++] = w;
+      w = nullptr;
+      if (hipExtMallocWithFlags((void**)&w, col_bytes, hipDeviceMallocContiguous) != hipSuccess) {
+        printf("contiguous allocation refused: %s\n", hipGetErrorString(hipGetLastError()));
+        w = held[--nheld];
+        break;
+      }
+      CHK(hipMemset(w, 0, col_bytes));
+      timeit("written vector, contiguous flag");
+    }
+    for (int k = 0; k < nheld; ++k) CHK(hipFree(held[k]));
+  }
   for (int k = 0; k < 4; ++k) {
     CHK(hipFree(V));
     CHK(hipMalloc(&V, col_bytes * ncols));
