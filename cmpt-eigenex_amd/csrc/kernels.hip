@@ -442,16 +442,40 @@ __device__ __forceinline__ TileRange spmv_tiles(int64_t ntiles, int xcd_sliced) 
   return TileRange{b, G, ntiles};
 }
 
+// InlineArnoldiBegin: returns true if the step must not run (the same test in every workgroup); *scale = 1/residue
+__device__ __forceinline__ bool arnoldi_begin_inline(const InlineArnoldiBegin& ab, double* scale) {
+  const int k = ab.ctrl->nvec;
+  const double res = ab.ctrl->residue;
+  const bool stop = (int64_t)k == ab.n_global || res <= ab.threshold || k >= ab.cap;  // arnoldiStepIsUtmost  arnoldi.hpp:277-288
+  *scale = 1.0 / res;                                                                   // arnoldi.hpp:365
+  return stop;
+}
+__device__ __forceinline__ void arnoldi_begin_record(const InlineArnoldiBegin& ab, bool stop, double scale) {
+  if (stop) {
+    ab.ctrl->stopped = 1;
+    return;
+  }
+  const int k = ab.ctrl->nvec;
+  ab.H[((int64_t)(k - 1) * ab.ldh + k) * ab.es] = ab.ctrl->residue;  // arnoldi.hpp:363 (imaginary part stays 0)
+  ab.ctrl->scale = scale;
+}
+
 __global__ __launch_bounds__(kBlock) void k_spmv(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                  const double* __restrict__ val, const double* __restrict__ x_ext,
                                                  const double* __restrict__ scale_ptr, double shift,
                                                  double* __restrict__ y, double* __restrict__ u_out, int64_t n,
                                                  int64_t ntiles, double* __restrict__ partials, int spmv_flags,
-                                                 int pass, const Ctrl* ctrl, InlineFin fin) {  // no __restrict__ on ctrl: fin.ctrl aliases it
+                                                 int pass, const Ctrl* ctrl, InlineFin fin, InlineArnoldiBegin ab) {  // no __restrict__ on ctrl: fin.ctrl / ab.ctrl alias it
   __shared__ double prod[kSpmvChunk + kSpmvChunk / 32 + 8];
   __shared__ double lds4[4];
   if (ctrl->stopped) return;
-  double scale = scale_ptr ? *scale_ptr : 1.0;
+  double scale = (scale_ptr && !ab.ctrl) ? *scale_ptr : 1.0;
+  if (ab.ctrl) {
+    const bool stop = arnoldi_begin_inline(ab, &scale);
+    __syncthreads();  // everybody has read the control block before workgroup 0 changes it (other workgroups: the values written are the ones they derived)
+    if (blockIdx.x == 0 && threadIdx.x == 0) arnoldi_begin_record(ab, stop, scale);
+    if (stop) return;
+  }
   if (fin.partials) {  // beta_k, the breakdown test and the scale of the operator input (lanczos.hpp:429-439), taken here
     const double nrm2 = inline_fin_sum(fin, lds4);
     const double nrm = sqrt(nrm2);
@@ -777,10 +801,16 @@ __device__ __forceinline__ void split_add(const SplitRegs& g, const double (&x)[
 // DEPTH = chunks whose gathers are in flight ahead of the adds (the entry streams run one chunk further ahead)
 template <int DEPTH>
 __global__ __launch_bounds__(kSplitBlock) void k_spmv_split(SplitOperatorView op, const double* __restrict__ x_ext,
-                                                           const double* __restrict__ scale_ptr, const Ctrl* __restrict__ ctrl) {
+                                                           const double* __restrict__ scale_ptr, const Ctrl* ctrl, InlineArnoldiBegin ab) {
   extern __shared__ double lds_acc[];  // tile_rows partial row sums
   if (ctrl->stopped) return;
-  const double scale = scale_ptr ? *scale_ptr : 1.0;
+  double scale = (scale_ptr && !ab.ctrl) ? *scale_ptr : 1.0;
+  if (ab.ctrl) {  // the second kernel (k_split_combine) reads the control block after workgroup 0 of this one has recorded
+    const bool stop = arnoldi_begin_inline(ab, &scale);
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) arnoldi_begin_record(ab, stop, scale);
+    if (stop) return;
+  }
   const int tid = threadIdx.x, T = op.tile_rows;
   const int wg = blockIdx.x, tile = wg / op.groups, grp = wg - tile * op.groups;
   const int c0 = op.wg_chunk[wg], c1 = op.wg_chunk[wg + 1];
@@ -1262,17 +1292,23 @@ __global__ void k_select_norm(const Ctrl* pass2, const double* nrm2_first, const
 
 // One shard: the sum of the first pass's norm partials and the DGKS decision in one launch
 __global__ __launch_bounds__(kBlock) void k_reduce_decide(const double* __restrict__ partials, int nblocks, double* nrm2_first,
-                                                          const Ctrl* ctrl, Ctrl* pass2, const double* nrm2_before, double eta2) {
+                                                          const Ctrl* ctrl, Ctrl* pass2, double* nrm2_before, double eta2,
+                                                          const double* __restrict__ before_partials, int before_nblocks) {
   __shared__ double lds4[4];
-  double s = 0.0;
-  if (!ctrl->stopped)
+  double s = 0.0, sb = 0.0;
+  if (!ctrl->stopped) {
     for (int b = threadIdx.x; b < nblocks; b += kBlock) s += partials[b];
+    if (before_partials)  // ||v||^2 of the operator's output, left as partial sums by the operator kernel: k_reduce's sum, taken here
+      for (int b = threadIdx.x; b < before_nblocks; b += kBlock) sb += before_partials[b];
+  }
   s = block_sum(s, lds4);
+  if (before_partials) sb = block_sum(sb, lds4);
   if (threadIdx.x != 0) return;
   if (ctrl->stopped) {
     pass2->stopped = 1;
     return;
   }
+  if (before_partials) *nrm2_before = sb;
   *nrm2_first = s;
   pass2->stopped = (s < eta2 * *nrm2_before) ? 0 : 1;
 }
@@ -1606,11 +1642,12 @@ void launch_reduce(hipStream_t s, const double* partials, int pstride, int nbloc
 
 void launch_spmv(hipStream_t s, const int32_t* rowptr, const int32_t* col, const double* val, const double* x_ext,
                  const double* scale, double shift, double* y, double* u_out, int64_t n, double* partials, int grid,
-                 const Ctrl* ctrl, int spmv_flags, int pass, const InlineFin* fin) {
+                 const Ctrl* ctrl, int spmv_flags, int pass, const InlineFin* fin, const InlineArnoldiBegin* begin) {
   const int64_t ntiles = (n + kSpmvRows - 1) / kSpmvRows;
   const InlineFin nofin{nullptr, 0, 0, 0.0, nullptr, nullptr, nullptr};
+  const InlineArnoldiBegin nobegin{nullptr, 0.0, 0, 0, nullptr, 0, 0};
   hipLaunchKernelGGL(k_spmv, dim3(grid), dim3(kBlock), 0, s, rowptr, col, val, x_ext, scale, shift, y, u_out, n,
-                     ntiles, partials, spmv_flags, pass, ctrl, fin ? *fin : nofin);
+                     ntiles, partials, spmv_flags, pass, ctrl, fin ? *fin : nofin, begin ? *begin : nobegin);
 }
 
 void launch_spmv_sorted(hipStream_t s, const SortedOperatorView& op, const double* x_ext, const double* scale, double shift, double* y,
@@ -1646,12 +1683,13 @@ bool prepare_spmv_split() {  // the kernel needs up to 128 KB of dynamic LDS: al
 }
 
 void launch_spmv_split(hipStream_t s, const SplitOperatorView& op, const double* x_ext, const double* scale, double shift, double* y,
-                       double* u_out, int64_t n, double* partials, const Ctrl* ctrl, int pass) {
+                       double* u_out, int64_t n, double* partials, const Ctrl* ctrl, int pass, const InlineArnoldiBegin* begin) {
   const auto kernel = k_spmv_split_used;
   (void)prepare_spmv_split();
+  const InlineArnoldiBegin nobegin{nullptr, 0.0, 0, 0, nullptr, 0, 0};
   const int64_t ntiles = (n + op.tile_rows - 1) / op.tile_rows;
   hipLaunchKernelGGL(kernel, dim3((unsigned)(ntiles * op.groups)), dim3(kSplitBlock), sizeof(double) * op.tile_rows, s, op, x_ext,
-                     scale, ctrl);
+                     scale, ctrl, begin ? *begin : nobegin);
   hipLaunchKernelGGL(k_split_combine, dim3(split_combine_grid(n)), dim3(kBlock), 0, s, op.part, op.part_stride, op.groups, x_ext, scale,
                      shift, y, u_out, n, partials, pass, ctrl);
 }
@@ -1729,8 +1767,9 @@ void launch_select_norm(hipStream_t s, const Ctrl* pass2, const double* nrm2_fir
 }
 
 void launch_reduce_decide(hipStream_t s, const double* partials, int nblocks, double* nrm2_first, const Ctrl* ctrl, Ctrl* pass2,
-                          const double* nrm2_before, double eta2) {
-  hipLaunchKernelGGL(k_reduce_decide, dim3(1), dim3(kBlock), 0, s, partials, nblocks, nrm2_first, ctrl, pass2, nrm2_before, eta2);
+                          double* nrm2_before, double eta2, const double* before_partials, int before_nblocks) {
+  hipLaunchKernelGGL(k_reduce_decide, dim3(1), dim3(kBlock), 0, s, partials, nblocks, nrm2_first, ctrl, pass2, nrm2_before, eta2,
+                     before_partials, before_nblocks);
 }
 void launch_arnoldi_tail(hipStream_t s, const double* partials, int nblocks, Ctrl* ctrl, const Ctrl* pass2, double* h, const double* h2,
                          int ncoef, const double* nrm2_first, double* nrm2_final, double* H, int ldh, int es) {

@@ -58,6 +58,19 @@ struct InlineFin {
   double* out;       // where k_reduce_fin would have left the sum (hbuf slot)
 };
 
+// The start of an Arnoldi step (k_arnoldi_begin: arnoldiStepIsUtmost arnoldi.hpp:277-288, h_{k,k-1} = residue :363, the
+// scale 1/residue :365) taken by the operator kernel itself, like InlineFin: every workgroup derives the same decision and
+// the same scale from the control block, workgroup 0 records them.  One launch less per Arnoldi step on one shard.
+// ctrl == nullptr: off.
+struct InlineArnoldiBegin {
+  Ctrl* ctrl;
+  double threshold;
+  int64_t n_global;
+  int cap;
+  double* H;
+  int ldh, es;
+};
+
 int grid_for_tiles(int64_t ntiles, int blocks_per_cu);
 void set_num_cu(int n);
 
@@ -91,7 +104,8 @@ enum { kPassCarry = 1, kPassNotLast = 2, kPassSelfNorm = 4 };
 // fin: beta_k = sqrt(sum of the update kernel's partials), breakdown test and scale = 1/beta_k taken inside this kernel
 void launch_spmv(hipStream_t s, const int32_t* rowptr, const int32_t* col, const double* val, const double* x_ext,
                  const double* scale, double shift, double* y, double* u_out, int64_t n, double* partials, int grid,
-                 const Ctrl* ctrl, int spmv_flags = 0, int pass = 0, const InlineFin* fin = nullptr);
+                 const Ctrl* ctrl, int spmv_flags = 0, int pass = 0, const InlineFin* fin = nullptr,
+                 const InlineArnoldiBegin* begin = nullptr);
 // Column-sorted row tiles (real fp64; kernels.hip: k_spmv_sorted): tile t = rows [t*T, (t+1)*T), T = tile_rows, slice k =
 // the k-th range of the operator input (global column order).  Segment (t, k) = entries base[t*(K+1)+k] .. base[t*(K+1)+k+1)
 // of cp/val, sorted by column, padded to a multiple of 4 (val 0, a spare slot); slot = place of the entry in row order
@@ -134,7 +148,7 @@ struct SplitOperatorView {
 int split_combine_grid(int64_t n);
 bool prepare_spmv_split();
 void launch_spmv_split(hipStream_t s, const SplitOperatorView& op, const double* x_ext, const double* scale, double shift, double* y,
-                       double* u_out, int64_t n, double* partials, const Ctrl* ctrl, int pass = 0);
+                       double* u_out, int64_t n, double* partials, const Ctrl* ctrl, int pass = 0, const InlineArnoldiBegin* begin = nullptr);
 // Block-sparse operator (the reference's BlockTensor<Scalar,2> layout, block_tensor.hpp:1193-1206, real or complex fp64):
 // 8 bytes per stored entry plus one column index per block COLUMN (4/rows bytes per entry) instead of CSR's 12.
 //   group g = the rows of one sector that this shard owns, rows grow0[g] .. grow0[g+1].  Its blocks, side by side,
@@ -195,8 +209,10 @@ void launch_add_small(hipStream_t s, double* dst, const double* src, int n, cons
 void launch_decide_second_pass(hipStream_t s, const Ctrl* ctrl, Ctrl* pass2, const double* nrm2_before, const double* nrm2_after, double eta2);
 void launch_select_norm(hipStream_t s, const Ctrl* pass2, const double* nrm2_first, const double* nrm2_second, double* nrm2_final);
 // single-shard merges of the tiny launches around the conditional second pass (see kernels.hip)
+// before_partials != nullptr: ||v||^2 before the pass is still the operator kernel's partial sums; they are added here (in
+// k_reduce's order) and the sum is left in *nrm2_before
 void launch_reduce_decide(hipStream_t s, const double* partials, int nblocks, double* nrm2_first, const Ctrl* ctrl, Ctrl* pass2,
-                          const double* nrm2_before, double eta2);
+                          double* nrm2_before, double eta2, const double* before_partials = nullptr, int before_nblocks = 0);
 void launch_arnoldi_tail(hipStream_t s, const double* partials, int nblocks, Ctrl* ctrl, const Ctrl* pass2, double* h, const double* h2,
                          int ncoef, const double* nrm2_first, double* nrm2_final, double* H, int ldh, int es);
 void launch_restart_fix(hipStream_t s, Ctrl* ctrl, double* alpha, double* beta, int m, int nkeep, double coupling_last);

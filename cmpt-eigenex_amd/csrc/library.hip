@@ -1186,7 +1186,7 @@ int enq_update(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_term, in
 // stage (*fin_merged = true) the caller must not launch k_fin_norm itself
 int enq_orthogonalize(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_term, int k, int first, int stride,
                       int count, int nq, bool q_first, bool norm_before = false, int fin_mode = -1, bool* fin_merged = nullptr,
-                      bool fused_alpha = false) {
+                      bool fused_alpha = false, bool before_in_palpha = false) {
   const int merge = (fin_mode >= 0 && fin_merged && decides_locally(b)) ? fin_mode : -1;
   if (fin_merged) *fin_merged = false;
   int mode = b->ortho_mode;
@@ -1199,7 +1199,8 @@ int enq_orthogonalize(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_t
     BasisShard& s = b->sh[0];
     CHK(enq_dots(b, src_ref, false, 0, first, stride, count, 0, nq, 0, 1));
     CHK(enq_update(b, src_ref, dst_ref, false, 0, first, stride, count, 0, nq, 0, false, 1));
-    launch_reduce_decide(st, s.partials, s.g_vec, s.hbuf + b->slot_nrm_first(), s.ctrl, s.ctrl_pass2, s.hbuf + b->slot_nrm_before(), 0.5);
+    launch_reduce_decide(st, s.partials, s.g_vec, s.hbuf + b->slot_nrm_first(), s.ctrl, s.ctrl_pass2, s.hbuf + b->slot_nrm_before(), 0.5,
+                         before_in_palpha ? s.palpha : nullptr, s.g_spmv);
     CHK(enq_dots(b, dst_ref, false, 0, first, stride, count, 0, nq, 0, 2, b->base_h2()));
     CHK(enq_update(b, dst_ref, dst_ref, false, 0, first, stride, count, 0, nq, 0, false, 2, b->base_h2()));
     launch_arnoldi_tail(st, s.partials, s.g_vec, s.ctrl, s.ctrl_pass2, s.hbuf, s.hbuf + b->base_h2(), (count + nq) * b->es,
@@ -1268,11 +1269,11 @@ int enq_orthogonalize(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_t
 // one operator application on one shard: a launch per column-block pass, the row sums carried in y
 void launch_operator(hipStream_t st, const CsrShard* m, int es, const double* x_ext, const double* scale, double shift,
                      double shift_im, double* y, double* u_out, double* partials, int pstride, int grid, const Ctrl* ctrl,
-                     int flags, int last_pass_flags = 0) {
+                     int flags, int last_pass_flags = 0, const InlineArnoldiBegin* begin = nullptr) {
   if (m->split) {
     const SplitOperatorView op{m->sp_wg, reinterpret_cast<const int4*>(m->sp_chunk), m->sp_cp, m->val, m->sp_groups, m->tile_rows,
                                m->s_nlow, m->npad, m->nloc, m->sp_part, m->npad};
-    launch_spmv_split(st, op, x_ext, scale, shift, y, u_out, m->nloc, partials, ctrl, last_pass_flags);
+    launch_spmv_split(st, op, x_ext, scale, shift, y, u_out, m->nloc, partials, ctrl, last_pass_flags, begin);
     return;
   }
   if (m->sorted) {
@@ -1297,7 +1298,7 @@ void launch_operator(hipStream_t st, const CsrShard* m, int es, const double* x_
                     grid, ctrl, flags, pass);
     else
       launch_spmv(st, rp, m->col, m->val, x_ext, scale, shift, y, u_out, m->nloc, last ? partials : nullptr, grid, ctrl, flags,
-                  pass);
+                  pass, nullptr, m->passes == 1 ? begin : nullptr);
   }
 }
 
@@ -1308,8 +1309,19 @@ void launch_operator(hipStream_t st, const CsrShard* m, int es, const double* x_
 // has been taken care of
 // defer_alpha (with want_dot, several shards): the shard's partial alpha is only summed locally into hbuf[base_fused()];
 // the all-reduce and k_fin_alpha happen with the next step's dots (enq_fused_dots)
+// can the operator kernel of this state take the start of an Arnoldi step itself (InlineArnoldiBegin)?  One shard that decides
+// locally, and an operator kernel that has the hook: plain real CSR in one pass, or split tiles
+bool inline_begin_ok(const eigenex_basis_s* b) {
+  if (!b->csr || !decides_locally(b) || b->sh.size() != 1) return false;
+  static const bool off = std::getenv("EIGENEX_NO_INLINE_FIN") != nullptr;
+  const CsrShard& m = b->csr->sh[0];
+  return !off && b->es == 1 && !m.blocked && !m.sorted && (m.split || m.passes == 1);
+}
+
+// defer_self_norm (with self_norm, one shard that decides locally): the partial sums of ||v||^2 stay in palpha for
+// k_reduce_decide, which adds them itself; begin: see InlineArnoldiBegin (only when inline_begin_ok)
 int enq_apply(eigenex_basis_s* b, int ucol, bool want_dot, bool self_norm = false, int alpha_mode = -1, bool* fin_merged = nullptr,
-              bool defer_alpha = false) {
+              bool defer_alpha = false, bool defer_self_norm = false, const InlineArnoldiBegin* begin = nullptr) {
   eigenex_context_s* c = b->ctx;
   const int merge = (want_dot && alpha_mode >= 0 && fin_merged && b->csr && decides_locally(b)) ? alpha_mode : -1;
   if (fin_merged) *fin_merged = merge >= 0;
@@ -1320,9 +1332,10 @@ int enq_apply(eigenex_basis_s* b, int ucol, bool want_dot, bool self_norm = fals
       if (self_norm) {
         {
           ProfScope ps(c, EIGENEX_K_SPMV, (m->blocked ? 8.0 * b->es * m->nnz + 4.0 * m->nstripcols + 4.0 * m->nloc : (4.0 + 8.0 * b->es) * m->nnz + 4.0 * (m->nloc + 1)) + 32.0 * s.nd);
-          launch_operator(c->stream, m, b->es, s.w, &s.ctrl->scale, b->shift, b->shift_im, s.v, s.V + (int64_t)ucol * s.ldd, s.partials,
-                          s.pstride, s.g_spmv, s.ctrl, s.spmv_flags, kPassSelfNorm);
+          launch_operator(c->stream, m, b->es, s.w, &s.ctrl->scale, b->shift, b->shift_im, s.v, s.V + (int64_t)ucol * s.ldd,
+                          defer_self_norm ? s.palpha : s.partials, s.pstride, s.g_spmv, s.ctrl, s.spmv_flags, kPassSelfNorm, begin);
         }
+        if (defer_self_norm) continue;
         ProfScope ps(c, EIGENEX_K_SMALL, 0.0);
         launch_reduce(c->stream, s.partials, s.pstride, s.g_spmv, 1, s.hbuf + b->slot_nrm_before(), s.ctrl);
         continue;
@@ -1331,7 +1344,7 @@ int enq_apply(eigenex_basis_s* b, int ucol, bool want_dot, bool self_norm = fals
         const double opbytes = m->blocked ? 8.0 * b->es * m->nnz + 4.0 * m->nstripcols + 4.0 * m->nloc : (4.0 + 8.0 * b->es) * m->nnz + 4.0 * (m->nloc + 1);
         ProfScope ps(c, EIGENEX_K_SPMV, opbytes + 32.0 * s.nd + (want_dot ? 16.0 * s.nd : 0.0));
         launch_operator(c->stream, m, b->es, s.w, &s.ctrl->scale, b->shift, b->shift_im, s.v, s.V + (int64_t)ucol * s.ldd,
-                        want_dot ? s.partials : nullptr, s.pstride, s.g_spmv, s.ctrl, s.spmv_flags);
+                        want_dot ? s.partials : nullptr, s.pstride, s.g_spmv, s.ctrl, s.spmv_flags, 0, begin);
       }
       if (want_dot) {
         ProfScope ps(c, EIGENEX_K_SMALL, 0.0);
@@ -1341,7 +1354,7 @@ int enq_apply(eigenex_basis_s* b, int ucol, bool want_dot, bool self_norm = fals
           launch_reduce(c->stream, s.partials, s.pstride, s.g_spmv, b->es, s.hbuf + (defer_alpha ? b->base_fused() : b->slot_alpha()), s.ctrl);
       }
     }
-    if (self_norm) return allreduce(b, b->slot_nrm_before(), 1);
+    if (self_norm) return defer_self_norm ? 0 : allreduce(b, b->slot_nrm_before(), 1);
     if (want_dot && defer_alpha) return 0;
     return want_dot && merge < 0 ? allreduce(b, b->slot_alpha(), b->es) : 0;
   }
@@ -1516,6 +1529,7 @@ int lanczos_call(eigenex_basis_s* b, bool last_in_batch) {
 int arnoldi_call(eigenex_basis_s* b) {
   hipStream_t st = b->ctx->stream;
   int k;
+  bool begin_inline = false;
   if (!b->started) {
     b->started = true;
     CHK(enq_initial_vector(b));
@@ -1523,16 +1537,23 @@ int arnoldi_call(eigenex_basis_s* b) {
   } else {
     k = b->h_nvec;
     if (k >= b->cap && (int64_t)k < b->n_global) return fail(EIGENEX_ERR_STATE, "basis capacity exhausted");
-    for (auto& s : b->sh) launch_arnoldi_begin(st, s.ctrl, b->threshold, b->n_global, b->cap, s.H, b->ldh, b->es);  // :357-365
+    // :357-365.  One shard with an operator kernel that has the hook: the operator kernel does this itself (one launch less)
+    begin_inline = k < b->cap && inline_begin_ok(b);
+    if (!begin_inline)
+      for (auto& s : b->sh) launch_arnoldi_begin(st, s.ctrl, b->threshold, b->n_global, b->cap, s.H, b->ldh, b->es);
     if (k >= b->cap) return 0;  // full Krylov space: the begin kernel has recorded "returned false"
   }
   const bool adaptive = b->ortho_mode == EIGENEX_ORTHO_BATCHED_ADAPTIVE && b->csr != nullptr;
-  CHK(enq_apply(b, k, false, adaptive));  // :333-336, :369-372
+  // one shard that decides locally: ||v||^2 stays as the operator's partial sums until k_reduce_decide (one launch less)
+  const bool small_merged = adaptive && decides_locally(b);
+  const InlineArnoldiBegin ab{b->sh[0].ctrl, b->threshold, b->n_global, b->cap, b->sh[0].H, b->ldh, b->es};
+  CHK(enq_apply(b, k, false, adaptive, -1, nullptr, false, small_merged, begin_inline ? &ab : nullptr));  // :333-336, :369-372
   if (!b->csr && b->shift != 0.0) { /* shift applied inside enq_apply's host path */ }
   // :337-345, :373-383
   bool tail_done = false;  // only the adaptive scheme on one shard folds k_fin_norm and k_arnoldi_end into its last launch
   if (adaptive)
-    CHK(enq_orthogonalize(b, EIGENEX_VEC_V, EIGENEX_VEC_W, false, 0, 0, 1, k + 1, b->nq, true, true, kFinArnoldi, &tail_done));
+    CHK(enq_orthogonalize(b, EIGENEX_VEC_V, EIGENEX_VEC_W, false, 0, 0, 1, k + 1, b->nq, true, true, kFinArnoldi, &tail_done, false,
+                          small_merged));
   else
     CHK(enq_orthogonalize(b, EIGENEX_VEC_V, EIGENEX_VEC_W, false, 0, 0, 1, k + 1, b->nq, true));
   if (!tail_done)
