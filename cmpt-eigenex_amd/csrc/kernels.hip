@@ -879,6 +879,119 @@ __device__ __forceinline__ double2 cmul_nofma(double2 a, double2 b) {
   return r;
 }
 
+// Split tiles, complex fp64: the same layout with 16-byte (re, im) values, inputs and accumulators (tiles of <= 8192 rows:
+// 128 KB of LDS); products are plain complex multiplies without contraction (like k_spmv_z), their parts are added to the row's
+// accumulator parts by two LDS atomics.
+struct SplitRegsZ {
+  uint4 c;
+  double2 v0, v1, v2, v3;
+  int nvalid;
+  int64_t pos0;
+};
+__device__ __forceinline__ void split_load_z(SplitRegsZ& g, const SplitOperatorView& op, int c, int c1, int tid) {
+  g.nvalid = 0;
+  if (c >= c1) return;
+  const int4 d = op.chunk[c];
+  const int q = d.x + 4 * tid;
+  g.nvalid = min(4, max(0, d.y - q));
+  g.pos0 = d.z;
+  if (g.nvalid > 0) {
+    const double* v = op.val + 2 * (int64_t)q;
+    g.c = *reinterpret_cast<const uint4*>(op.cp + q);
+    g.v0 = nt_ld_d2(v), g.v1 = nt_ld_d2(v + 2), g.v2 = nt_ld_d2(v + 4), g.v3 = nt_ld_d2(v + 6);
+  }
+}
+__device__ __forceinline__ void split_gather_z(double2 (&x)[4], const SplitRegsZ& g, const SplitOperatorView& op,
+                                               const double2* __restrict__ x_ext) {
+  x[0] = x[1] = x[2] = x[3] = make_double2(0.0, 0.0);
+  if (g.nvalid > 0) x[0] = x_ext[split_index(op, g.pos0, g.c.x)];
+  if (g.nvalid > 1) x[1] = x_ext[split_index(op, g.pos0, g.c.y)];
+  if (g.nvalid > 2) x[2] = x_ext[split_index(op, g.pos0, g.c.z)];
+  if (g.nvalid > 3) x[3] = x_ext[split_index(op, g.pos0, g.c.w)];
+}
+__device__ __forceinline__ void split_add1_z(double* acc, unsigned c, double2 v, double2 x, double scale) {
+  const double2 p = cmul_nofma(v, make_double2(x.x * scale, x.y * scale));
+  double* a = acc + 2 * (int64_t)(c >> kSplitRelBits);
+  split_add1(a, p.x);
+  split_add1(a + 1, p.y);
+}
+__global__ __launch_bounds__(kSplitBlock) void k_spmv_split_z(SplitOperatorView op, const double2* __restrict__ x_ext,
+                                                             const double* __restrict__ scale_ptr, const Ctrl* __restrict__ ctrl) {
+  extern __shared__ double lds_acc[];  // tile_rows (re, im) pairs
+  if (ctrl->stopped) return;
+  const double scale = scale_ptr ? *scale_ptr : 1.0;
+  const int tid = threadIdx.x, T = op.tile_rows;
+  const int wg = blockIdx.x, tile = wg / op.groups, grp = wg - tile * op.groups;
+  const int c0 = op.wg_chunk[wg], c1 = op.wg_chunk[wg + 1];
+  SplitRegsZ r0, r1, r2;
+  double2 x0[4], x1[4];
+  split_load_z(r0, op, c0, c1, tid);
+  split_load_z(r1, op, c0 + 1, c1, tid);
+  split_gather_z(x0, r0, op, x_ext);
+  for (int i = tid; i < 2 * T; i += kSplitBlock) lds_acc[i] = 0.0;
+  __syncthreads();
+  for (int c = c0; c < c1; ++c) {
+    split_load_z(r2, op, c + 2, c1, tid);
+    split_gather_z(x1, r1, op, x_ext);
+    if (r0.nvalid > 0) split_add1_z(lds_acc, r0.c.x, r0.v0, x0[0], scale);
+    if (r0.nvalid > 1) split_add1_z(lds_acc, r0.c.y, r0.v1, x0[1], scale);
+    if (r0.nvalid > 2) split_add1_z(lds_acc, r0.c.z, r0.v2, x0[2], scale);
+    if (r0.nvalid > 3) split_add1_z(lds_acc, r0.c.w, r0.v3, x0[3], scale);
+    __syncthreads();  // the next chunk may hold the same rows
+    r0 = r1, r1 = r2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x0[i] = x1[i];
+  }
+  const int64_t r0w = (int64_t)tile * T;
+  double* dst = op.part + 2 * ((int64_t)grp * op.part_stride + r0w);
+  for (int i = tid; i < 2 * T; i += kSplitBlock)
+    if (r0w + (i >> 1) < op.nloc) dst[i] = lds_acc[i];
+}
+
+__global__ __launch_bounds__(kBlock) void k_split_combine_z(const double2* __restrict__ part, int64_t part_stride, int groups,
+                                                           const double2* __restrict__ x_ext, const double* __restrict__ scale_ptr,
+                                                           double shift_re, double shift_im, double2* __restrict__ y,
+                                                           double2* __restrict__ u_out, int64_t n, double* __restrict__ partials,
+                                                           int pstride, int pass, const Ctrl* __restrict__ ctrl) {
+  __shared__ double lds4[4];
+  if (ctrl->stopped) return;
+  const double scale = scale_ptr ? *scale_ptr : 1.0;
+  const bool has_shift = shift_re != 0.0 || shift_im != 0.0;
+  double dr = 0.0, di = 0.0;
+  for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
+    double2 yr = part[r];
+    for (int g = 1; g < groups; ++g) {  // ascending group order
+      const double2 t = part[(int64_t)g * part_stride + r];
+      yr.x = yr.x + t.x;
+      yr.y = yr.y + t.y;
+    }
+    double2 xr = x_ext[r];
+    xr.x *= scale;
+    xr.y *= scale;
+    if (has_shift) {
+      const double2 t = cmul_nofma(make_double2(shift_re, shift_im), xr);
+      yr.x = yr.x + t.x;
+      yr.y = yr.y + t.y;
+    }
+    y[r] = yr;
+    if (u_out) u_out[r] = xr;
+    if (pass & kPassSelfNorm) {
+      dr = fma(yr.x, yr.x, fma(yr.y, yr.y, dr));  // |y|^2
+    } else {
+      dr = fma(xr.x, yr.x, fma(xr.y, yr.y, dr));  // conj(u) * y
+      di = fma(xr.x, yr.y, fma(-xr.y, yr.x, di));
+    }
+  }
+  if (partials) {
+    dr = block_sum(dr, lds4);
+    di = block_sum(di, lds4);
+    if (threadIdx.x == 0) {
+      partials[blockIdx.x] = dr;
+      partials[pstride + blockIdx.x] = di;
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void k_spmv_z(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                    const double2* __restrict__ val, const double2* __restrict__ x_ext,
                                                    const double* __restrict__ scale_ptr, double shift_re,
@@ -1678,6 +1791,8 @@ int split_combine_grid(int64_t n) { return grid_for_tiles((n + 2 * kBlock - 1) /
 static const auto k_spmv_split_used = k_spmv_split<1>;
 bool prepare_spmv_split() {  // the kernel needs up to 128 KB of dynamic LDS: allowed once, at upload (not inside a stream capture)
   static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmv_split_used), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)(sizeof(double) * kSplitMaxTileRows)) == hipSuccess &&
+                         hipFuncSetAttribute(reinterpret_cast<const void*>(k_spmv_split_z), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)(sizeof(double) * kSplitMaxTileRows)) == hipSuccess;
   return ok;
 }
@@ -1692,6 +1807,17 @@ void launch_spmv_split(hipStream_t s, const SplitOperatorView& op, const double*
                      scale, ctrl, begin ? *begin : nobegin);
   hipLaunchKernelGGL(k_split_combine, dim3(split_combine_grid(n)), dim3(kBlock), 0, s, op.part, op.part_stride, op.groups, x_ext, scale,
                      shift, y, u_out, n, partials, pass, ctrl);
+}
+
+void launch_spmv_split_z(hipStream_t s, const SplitOperatorView& op, const double* x_ext, const double* scale, double shift_re,
+                         double shift_im, double* y, double* u_out, int64_t n, double* partials, int pstride, const Ctrl* ctrl, int pass) {
+  (void)prepare_spmv_split();
+  const int64_t ntiles = (n + op.tile_rows - 1) / op.tile_rows;
+  hipLaunchKernelGGL(k_spmv_split_z, dim3((unsigned)(ntiles * op.groups)), dim3(kSplitBlock), sizeof(double) * 2 * op.tile_rows, s, op,
+                     reinterpret_cast<const double2*>(x_ext), scale, ctrl);
+  hipLaunchKernelGGL(k_split_combine_z, dim3(split_combine_grid(n)), dim3(kBlock), 0, s, reinterpret_cast<const double2*>(op.part),
+                     op.part_stride, op.groups, reinterpret_cast<const double2*>(x_ext), scale, shift_re, shift_im,
+                     reinterpret_cast<double2*>(y), reinterpret_cast<double2*>(u_out), n, partials, pstride, pass, ctrl);
 }
 
 int sorted_grid(int64_t n, int tile_rows) { return grid_for_tiles((n + tile_rows - 1) / tile_rows, 1); }

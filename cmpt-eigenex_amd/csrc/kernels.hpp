@@ -145,6 +145,9 @@ struct SplitOperatorView {
   double* part;
   int64_t part_stride;
 };
+// complex: val / x / y / u_out / part hold (re, im) pairs, tile_rows <= 8192; partials as launch_spmv_z
+void launch_spmv_split_z(hipStream_t s, const SplitOperatorView& op, const double* x_ext, const double* scale, double shift_re,
+                         double shift_im, double* y, double* u_out, int64_t n, double* partials, int pstride, const Ctrl* ctrl, int pass = 0);
 int split_combine_grid(int64_t n);
 bool prepare_spmv_split();
 void launch_spmv_split(hipStream_t s, const SplitOperatorView& op, const double* x_ext, const double* scale, double shift, double* y,

@@ -715,22 +715,26 @@ int build_shard_host(eigenex_context_s* c, int64_t n_global, int gshard, const i
   // when a tile has >= 3 gathers per 128-byte input line, unless EIGENEX_EXACT_ROW_SUMS is set): the fastest, row sums
   // re-associated.  Column-sorted row tiles (-2: asked for; -1: when eligible): bit-identical to the row loop.  Else
   // column-blocked passes (2..16: asked for).
-  const bool scattered = column_blocks == -1 && es == 1 && (s.nloc + s.nhalo) * 8 > kSliceBytes && s.nnz / std::max<int64_t>(s.nloc, 1) >= 6 &&
-                         gathers_scattered(s, lcol, lrp);
-  if (column_blocks == -3 || scattered) {
+  // (complex operators: the same conditions on an input of 16-byte elements; split tiles of <= 8192 rows, no sorted tiles)
+  const bool scattered_any = column_blocks == -1 && (s.nloc + s.nhalo) * 8 * es > kSliceBytes && s.nnz / std::max<int64_t>(s.nloc, 1) >= 6 &&
+                             gathers_scattered(s, lcol, lrp);
+  const bool scattered = scattered_any && es == 1;
+  if (column_blocks == -3 || scattered_any) {
     static const bool exact = std::getenv("EIGENEX_EXACT_ROW_SUMS") != nullptr;
     int T = 0, G = 0;
     bool want = false;
+    const int max_T = kSplitMaxTileRows / es;
     if (column_blocks == -3) {
-      if (es != 1) return fail(EIGENEX_ERR_ARG, "split tiles need a real operator");
       for (int wgs : {240, 64, 8, 1})
-        if ((want = split_geometry(s.nloc, wgs, 256, &T, &G))) break;
-    } else if (!exact && split_geometry(s.nloc, 240, 4096, &T, &G)) {
-      want = (double)T * (double)s.nnz / (double)s.nloc * 16.0 >= 3.0 * (double)(s.nloc + s.nhalo);
+        if ((want = split_geometry(s.nloc, wgs, 256, &T, &G, max_T))) break;
+    } else if (!exact && split_geometry(s.nloc, 240, 4096, &T, &G, max_T)) {
+      // gathers per 128-byte input line of a tile: >= 3 (real; below that the column-sorted tiles are as good), >= 2 (complex,
+      // where the alternative is column-blocked passes: measured 289 vs 345 us at 2.1 on config 3's pattern with complex values)
+      want = (double)T * (double)s.nnz / (double)s.nloc * (16.0 / es) >= (es == 1 ? 3.0 : 2.0) * (double)(s.nloc + s.nhalo);
     }
     SplitLayout L;
     const GlobalOrder order(s);
-    if (want && build_split_layout(s.nloc, s.nloc + s.nhalo, lrp.data(), lcol.data(), vsrc, order, T, G, L)) {
+    if (want && build_split_layout(s.nloc, s.nloc + s.nhalo, lrp.data(), lcol.data(), vsrc, order, T, G, L, es)) {
       if (!prepare_spmv_split()) return fail(EIGENEX_ERR_HIP, "k_spmv_split: 128 KB of dynamic LDS refused");
       s.split = true;
       s.sp_groups = L.G;
@@ -740,8 +744,8 @@ int build_shard_host(eigenex_context_s* c, int64_t n_global, int gshard, const i
       CHK(upload_vec(c, &s.sp_chunk, L.chunk, 8));
       CHK(upload_vec(c, &s.sp_cp, L.cp, 8));
       CHK(upload_vec(c, &s.val, L.val, 8));
-      HIPCHK(hipMalloc(&s.sp_part, sizeof(double) * (size_t)s.npad * L.G));
-      HIPCHK(hipMemsetAsync(s.sp_part, 0, sizeof(double) * (size_t)s.npad * L.G, c->stream));
+      HIPCHK(hipMalloc(&s.sp_part, sizeof(double) * (size_t)s.npad * L.G * es));
+      HIPCHK(hipMemsetAsync(s.sp_part, 0, sizeof(double) * (size_t)s.npad * L.G * es, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));
       return 0;
     }
@@ -1273,7 +1277,10 @@ void launch_operator(hipStream_t st, const CsrShard* m, int es, const double* x_
   if (m->split) {
     const SplitOperatorView op{m->sp_wg, reinterpret_cast<const int4*>(m->sp_chunk), m->sp_cp, m->val, m->sp_groups, m->tile_rows,
                                m->s_nlow, m->npad, m->nloc, m->sp_part, m->npad};
-    launch_spmv_split(st, op, x_ext, scale, shift, y, u_out, m->nloc, partials, ctrl, last_pass_flags, begin);
+    if (es == 2)
+      launch_spmv_split_z(st, op, x_ext, scale, shift, shift_im, y, u_out, m->nloc, partials, pstride, ctrl, last_pass_flags);
+    else
+      launch_spmv_split(st, op, x_ext, scale, shift, y, u_out, m->nloc, partials, ctrl, last_pass_flags, begin);
     return;
   }
   if (m->sorted) {

@@ -37,10 +37,10 @@ struct SplitLayout {
   std::vector<double> val;
 };
 
-// rows per tile (a power of two, min_T .. 16384) and groups for a shard of nloc rows: the largest tile that still gives
-// >= want_wgs workgroups with <= 8 groups
-inline bool split_geometry(int64_t nloc, int want_wgs, int min_T, int* T, int* G) {
-  for (int t = kSplitMaxTileRows; t >= min_T; t /= 2) {
+// rows per tile (a power of two, min_T .. max_T; max_T = 16384 real, 8192 complex: 128 KB of accumulators) and groups for a
+// shard of nloc rows: the largest tile that still gives >= want_wgs workgroups with <= 8 groups
+inline bool split_geometry(int64_t nloc, int want_wgs, int min_T, int* T, int* G, int max_T = kSplitMaxTileRows) {
+  for (int t = max_T; t >= min_T; t /= 2) {
     const int64_t ntiles = (nloc + t - 1) / t;
     if (ntiles * kSplitMaxGroups < want_wgs) continue;
     *T = t;
@@ -55,14 +55,14 @@ inline bool split_geometry(int64_t nloc, int want_wgs, int min_T, int* T, int* G
 // entries in one group, offsets beyond int32).
 template <class Order>
 bool build_split_layout(int64_t nloc, int64_t ext, const int32_t* lrp, const int32_t* lcol, const double* val, const Order& order,
-                        int T, int G, SplitLayout& L) {
-  if (nloc <= 0 || T > kSplitMaxTileRows || G < 1 || G > kSplitMaxGroups || ext <= 0 || ext > (int64_t)2147483647) return false;
+                        int T, int G, SplitLayout& L, int es = 1) {  // es doubles per stored value: 1 real, 2 complex (re, im)
+  if (nloc <= 0 || T > kSplitMaxTileRows / es || G < 1 || G > kSplitMaxGroups || ext <= 0 || ext > (int64_t)2147483647 || es < 1 || es > 2) return false;
   const int64_t ntiles = (nloc + T - 1) / T;
   const int64_t Wg = (ext + G - 1) / G;
   struct Ent {
     uint32_t pg;   // position inside the group
     uint32_t row;  // row inside the tile
-    double val;
+    int32_t src;   // index of the entry in the shard's CSR arrays
   };
   struct Piece {
     std::vector<uint32_t> cp;
@@ -78,7 +78,7 @@ bool build_split_layout(int64_t nloc, int64_t ext, const int32_t* lrp, const int
     const int64_t t0 = ntiles * th / nthreads, t1 = ntiles * (th + 1) / nthreads;
     const size_t guess = (size_t)((int64_t)lrp[std::min<int64_t>(t1 * T, nloc)] - lrp[std::min<int64_t>(t0 * T, nloc)]);
     P.cp.reserve(guess + guess / 64 + 1024);
-    P.val.reserve(guess + guess / 64 + 1024);
+    P.val.reserve((guess + guess / 64 + 1024) * (size_t)es);
     std::vector<std::vector<Ent>> grp((size_t)G);
     std::vector<Ent> tmp, cur, pending, next_pending;
     std::vector<int32_t> stamp((size_t)T, -1);
@@ -90,7 +90,7 @@ bool build_split_layout(int64_t nloc, int64_t ext, const int32_t* lrp, const int
         for (int64_t p = lrp[r]; p < lrp[r + 1]; ++p) {
           const int64_t pos = order(lcol[p]);
           const int64_t g = pos / Wg;
-          grp[(size_t)g].push_back(Ent{(uint32_t)(pos - g * Wg), (uint32_t)(r - r0), val[p]});
+          grp[(size_t)g].push_back(Ent{(uint32_t)(pos - g * Wg), (uint32_t)(r - r0), (int32_t)p});
         }
       for (int g = 0; g < G; ++g) {
         auto& v = grp[(size_t)g];
@@ -146,13 +146,16 @@ bool build_split_layout(int64_t nloc, int64_t ext, const int32_t* lrp, const int
           P.chunk.push_back(0);
           auto put = [&](const Ent& e) {
             P.cp.push_back((e.pg - first) | (e.row << kSplitRelBits));
-            P.val.push_back(e.val);
+            for (int c = 0; c < es; ++c) P.val.push_back(val[(int64_t)e.src * es + c]);
           };
           const size_t full = cur.size() / 256 * 256;
           for (size_t b0 = 0; b0 < full; b0 += 256)
             for (size_t q = 0; q < 256; ++q) put(cur[b0 + 64 * (q & 3) + (q >> 2)]);
           for (size_t q = full; q < cur.size(); ++q) put(cur[q]);
-          while (P.cp.size() & 3) P.cp.push_back(0), P.val.push_back(0.0);
+          while (P.cp.size() & 3) {
+            P.cp.push_back(0);
+            for (int c = 0; c < es; ++c) P.val.push_back(0.0);
+          }
         }
       }
     }
@@ -185,7 +188,7 @@ bool build_split_layout(int64_t nloc, int64_t ext, const int32_t* lrp, const int
   if (total > (size_t)2147483647 - 16384) return false;
   L.T = T, L.G = G, L.ntiles = ntiles;
   L.cp.clear(), L.val.clear(), L.chunk.clear(), L.wg_chunk.clear();
-  L.cp.reserve(total), L.val.reserve(total), L.chunk.reserve(4 * nchunks + 8), L.wg_chunk.reserve((size_t)ntiles * G + 1);
+  L.cp.reserve(total), L.val.reserve(total * (size_t)es), L.chunk.reserve(4 * nchunks + 8), L.wg_chunk.reserve((size_t)ntiles * G + 1);
   for (auto& P : pieces) {
     const int32_t eshift = (int32_t)L.cp.size(), cshift = (int32_t)(L.chunk.size() / 4);
     for (int32_t w : P.wg_first) L.wg_chunk.push_back(w + cshift);
@@ -201,7 +204,8 @@ bool build_split_layout(int64_t nloc, int64_t ext, const int32_t* lrp, const int
     std::vector<double>().swap(P.val);
   }
   L.wg_chunk.push_back((int32_t)(L.chunk.size() / 4));
-  for (int i = 0; i < 8; ++i) L.cp.push_back(0), L.val.push_back(0.0);  // 16-byte loads may run past the end
+  for (int i = 0; i < 8; ++i) L.cp.push_back(0);  // 16-byte loads may run past the end
+  for (int i = 0; i < 8 * es; ++i) L.val.push_back(0.0);
   for (int i = 0; i < 8; ++i) L.chunk.push_back(0);                    // descriptors are read two chunks ahead
   return true;
 }

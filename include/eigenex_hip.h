@@ -206,7 +206,9 @@ int eigenex_csr_upload_z(eigenex_context_t ctx, int64_t n_global, int64_t row_be
  *                       column-sorted entries into partial row sums in LDS, a second kernel adds the <= 8 partial sums of a
  *                       row in ascending group order.  The ONLY layout that re-associates a row's sum: y differs from the
  *                       row loop by a few ulp of sum |a_ij x_j| (products are still rounded before they are added), the
- *                       same bits on every run.  1.35x over the column-sorted tiles on BASELINE config 3.  Real operators;
+ *                       same bits on every run.  1.35x over the column-sorted tiles on BASELINE config 3.  Real and complex
+ *                       operators (complex: tiles of 8192 rows, taken automatically from 2 gathers per line; 1.2x over the
+ *                       column-blocked passes on config 3's pattern with complex values);
  *                       error if a row has thousands of entries in one column group.  Setting the environment variable
  *                       EIGENEX_EXACT_ROW_SUMS keeps the automatic mode to the layouts that are bit-identical to the row loop */
 int eigenex_csr_upload_ex(eigenex_context_t ctx, int64_t n_global, int64_t row_begin, int64_t n_rows,

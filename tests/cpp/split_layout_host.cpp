@@ -110,6 +110,26 @@ int main() {
     auto ident = [](int64_t lc) { return lc; };
     if (build_split_layout(n, n, rp.data(), col.data(), val.data(), ident, 1024, 2, L)) rc |= fail("dense row accepted");
   }
+  {  // two doubles per value (complex): every entry's pair travels with its index; tiles of <= 8192 rows
+    const int64_t n = 3000;
+    std::mt19937_64 rng(9);
+    std::vector<int32_t> rp((size_t)n + 1, 0), col;
+    std::vector<double> val;
+    for (int64_t r = 0; r < n; ++r) {
+      const int len = (int)(rng() % 12);
+      for (int k = 0; k < len; ++k) col.push_back((int32_t)(rng() % (uint64_t)n)), val.push_back((double)col.size()), val.push_back(-(double)col.size());
+      rp[(size_t)r + 1] = (int32_t)col.size();
+    }
+    SplitLayout L;
+    auto ident = [](int64_t lc) { return lc; };
+    if (build_split_layout(n, n, rp.data(), col.data(), val.data(), ident, 16384, 2, L, 2)) rc |= fail("complex tile of 16384 rows accepted");
+    if (!build_split_layout(n, n, rp.data(), col.data(), val.data(), ident, 1024, 3, L, 2)) rc |= fail("complex layout not built");
+    size_t used = 0;
+    for (size_t c = 0; c + 2 < L.chunk.size() / 4; ++c)
+      for (int32_t q = L.chunk[4 * c]; q < L.chunk[4 * c + 1]; ++q, ++used)
+        if (L.val[2 * (size_t)q] <= 0.0 || L.val[2 * (size_t)q + 1] != -L.val[2 * (size_t)q]) rc |= fail("complex value pair torn", q);
+    if (used != col.size()) rc |= fail("complex entries used", (long)used, (long)col.size());
+  }
   if (!rc) std::printf("SPLIT LAYOUT OK\n");
   return rc;
 }

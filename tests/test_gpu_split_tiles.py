@@ -191,3 +191,61 @@ print(A.layout(), int(np.count_nonzero(y != y_ref)), float(np.abs(y - y_ref).max
         out[exact] = r.stdout.split()[-3:]
     assert out[False][0] == "split_tiles" and float(out[False][2]) < 1e-13
     assert out[True][0] in ("sorted_tiles", "column_blocked", "csr") and int(out[True][1]) == 0
+
+
+@pytest.mark.parametrize("shards", [1, 2])
+def test_split_tiles_complex(capi, shards):
+    """k_spmv_split_z + k_split_combine_z (complex fp64, the scalar type of the reference's samples): Gaussian-integer data are
+    exact under every association -> bit-identical to scipy's row sums; random data within a rounding-level bound of them, the
+    same bits on a second application, complex shift, the fused conj(x).y dot; an Arnoldi run against the plain CSR layout."""
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(900 + shards)
+    for n, top in ((9_001, 30), (150_000, 14)):
+        rowptr, col, _ = ragged(rng, n, top, 6, 90)
+        nnz = int(rowptr[-1])
+        vi = rng.integers(-6, 7, nnz) + 1j * rng.integers(-6, 7, nnz)
+        xi = rng.integers(-3, 4, n) + 1j * rng.integers(-3, 4, n)
+        vr = rng.uniform(-1, 1, nnz) + 1j * rng.uniform(-1, 1, nnz)
+        xr = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+        ctx = capi.Context(loopback_shards=shards) if shards > 1 else capi.Context()
+        for val, x, exact in ((vi, xi, True), (vr, xr, False)):
+            val = val.astype(np.complex128)
+            x = x.astype(np.complex128)
+            Asp = sp.csr_matrix((val, col, rowptr), shape=(n, n))
+            y_ref = Asp @ x
+            A = capi.Csr.upload(ctx, n, rowptr, col, val, column_blocks=-3)
+            assert A.layout() == "split_tiles" and A.is_complex
+            b = capi.Basis(ctx, A, n, 2, dtype=np.complex128)
+            b.upload(capi.VEC_W, x)
+            dot = b.apply(capi.VEC_W, capi.VEC_V, 0.0, want_dot=True)
+            y = b.download(capi.VEC_V)
+            if exact:
+                np.testing.assert_array_equal(y, y_ref)
+                assert dot == np.vdot(x, y_ref)
+            else:
+                mag = abs(Asp) @ np.abs(x)
+                assert np.all(np.abs(y - y_ref) <= 64 * EPS * mag)
+                assert abs(dot - np.vdot(x, y)) <= 1e-13 * np.linalg.norm(x) * np.linalg.norm(y)
+                b.apply(capi.VEC_W, capi.VEC_V, 0.0)
+                np.testing.assert_array_equal(b.download(capi.VEC_V), y)
+                b.apply(capi.VEC_W, capi.VEC_V, -0.375)  # the primitive takes a real shift; a complex one runs in the Arnoldi steps below
+                ysh = b.download(capi.VEC_V)
+                assert np.all(np.abs(ysh - (y - 0.375 * x)) <= 8 * EPS * (np.abs(y) + np.abs(x)))
+            b.close()
+            A.close()
+        # Arnoldi: split tiles against plain CSR
+        H = {}
+        for K in (-3, 0):
+            A = capi.Csr.upload(ctx, n, rowptr, col, vr.astype(np.complex128), column_blocks=K)
+            b = capi.Basis(ctx, A, n, 12, dtype=np.complex128)
+            b.configure(0.2 - 0.1j, 1e-12, 1, capi.ORTHO_BATCHED_ADAPTIVE)
+            b.upload(capi.VEC_W, xr.astype(np.complex128))
+            b.arnoldi_enqueue(12)
+            st, h = b.arnoldi_state()
+            assert st.nvec == 12 and st.stopped == 0
+            H[K] = h.copy()
+            b.close()
+            A.close()
+        assert np.abs(H[-3] - H[0]).max() <= 1e-10 * np.abs(H[0]).max()
+        ctx.close()
