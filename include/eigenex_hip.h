@@ -196,7 +196,7 @@ int eigenex_csr_upload_z(eigenex_context_t ctx, int64_t n_global, int64_t row_be
  *                       exceeds L2, rows are long enough and the gathers are scattered; -3, -2 or blocked passes, in that
  *                       order of preference (the last two only when the result stays bit-identical)
  *   column_blocks = 0,1 never;  2..16: that many passes, unconditionally
- *   column_blocks = -2  column-sorted row tiles (what the automatic mode prefers for real operators since round 2): the
+ *   column_blocks = -2  column-sorted row tiles (the automatic mode's choice among the bit-identical layouts, real operators): the
  *                       entries of every (4096-row tile, 256 KB input slice) are stored sorted by column, so that the lanes
  *                       of a wave gather from shared 128-byte lines, with a 16-bit slot that restores the row order for
  *                       the sums; one launch, slices walked inside the kernel, bit-identical to the row loop.  Needs a
