@@ -56,6 +56,13 @@ for r in range(rounds):
     sa = solver.ArnoldiEigenSolver()
     sa.setDeviceOperator(S).set(minIterations=12, maxIterations=12, maxEigenvalues=2)
     sa.compute(); sa.close()
+    for cplx in (False, True):  # split tiles, real and complex
+        vv = vls if not cplx else (vls + 1j * vls[::-1]).astype(np.complex128)
+        P = capi.Csr.upload(ctx, Ns, rps.astype(np.int32), cls, vv, column_blocks=-3)
+        assert P.layout() == "split_tiles"
+        pa = solver.ArnoldiEigenSolver(np.complex128) if cplx else solver.ArnoldiEigenSolver()
+        pa.setDeviceOperator(P).set(minIterations=12, maxIterations=12, maxEigenvalues=2)
+        pa.compute(); pa.close(); P.close()
     bb = capi.Basis(ctx, S, Ns, 6)
     bb.upload(capi.VEC_W, rng.standard_normal(Ns)); bb.lanczos_enqueue(5)
     import ctypes as C
