@@ -25,6 +25,22 @@ __global__ __launch_bounds__(256) void k_read_many_write_one(const double2* __re
   }
 }
 
+template <int U>
+__global__ __launch_bounds__(256) void k_read_many(const double2* __restrict__ p, size_t col_n2, int ncols, double* out) {
+  const size_t stride = (size_t)gridDim.x * 256 * U;
+  double s = 0.0;
+  for (size_t i = (size_t)blockIdx.x * 256 * U + threadIdx.x; i < col_n2; i += stride)
+    for (int c = 0; c < ncols; ++c) {
+      const double2* pc = p + (size_t)c * col_n2;
+      double2 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = (i + u * 256 < col_n2) ? pc[i + u * 256] : make_double2(0, 0);
+#pragma unroll
+      for (int u = 0; u < U; ++u) s += v[u].x + v[u].y;
+    }
+  if (s == 12345.678) out[0] = s;
+}
+
 int main(int argc, char** argv) {
   const int ncols = argc > 1 ? atoi(argv[1]) : 24;
   const size_t col_bytes = (size_t)1 << 30, cn2 = col_bytes / 16;
@@ -84,11 +100,32 @@ int main(int argc, char** argv) {
     }
     for (int k = 0; k < nheld; ++k) CHK(hipFree(held[k]));
   }
-  for (int k = 0; k < 4; ++k) {
-    CHK(hipFree(V));
-    CHK(hipMalloc(&V, col_bytes * ncols));
-    CHK(hipMemset(V, 1, col_bytes * ncols));
-    timeit("column slab re-allocated");
+  auto time_read = [&](const char* what) {
+    float best = 1e30f;
+    for (int r = 0; r < 4; ++r) {
+      (void)hipEventRecord(e0);
+      hipLaunchKernelGGL(k_read_many<4>, dim3(512), dim3(256), 0, 0, V, cn2, ncols, (double*)w);
+      (void)hipEventRecord(e1);
+      (void)hipEventSynchronize(e1);
+      float ms;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      if (ms < best) best = ms;
+    }
+    printf("%-34s V=%p  %7.3f ms  %6.0f GB/s (read only)\n", what, (void*)V, best, (double)ncols * col_bytes / 1e9 / (best * 1e-3));
+    fflush(stdout);
+  };
+  time_read("slab as allocated first");
+  {  // distinct frames for the slab: allocate another while the first is held, compare, swap
+    for (int k = 0; k < 5; ++k) {
+      double2* V2 = nullptr;
+      if (hipMalloc(&V2, col_bytes * ncols) != hipSuccess) { printf("no room for a second slab\n"); break; }
+      CHK(hipMemset(V2, 1, col_bytes * ncols));
+      double2* old = V;
+      V = V2;
+      time_read("slab on new frames");
+      timeit("  read + write with it");
+      CHK(hipFree(old));
+    }
   }
   return 0;
 }
