@@ -111,8 +111,8 @@ bool build_split_layout(int64_t nloc, int64_t ext, const int32_t* lrp, const int
         size_t i = 0, made = 0;
         pending.clear();
         while (i < n || !pending.empty()) {
-          if (++made > max_chunks) {  // a row with very many entries in this group: one chunk per entry of it
-            P.ok = false;
+          if (++made > max_chunks || P.cp.size() > (size_t)2147483647 - 65536) {  // a row with very many entries in this group (one chunk
+            P.ok = false;                                                            // per entry of it), or 32-bit entry offsets exhausted
             return;
           }
           ++chunk_id;
