@@ -388,3 +388,39 @@ def test_config5_block_hamiltonian_5e7_thick_restart(capi):
     assert np.all(np.diff(rp) == 3 * bsz)
     np.testing.assert_array_equal(y_blocks[r0:r1], y_ref)
     ctx.close()
+
+
+def test_placement_probe_changes_no_result():
+    """State creation times candidate allocations for the vectors written in every step when they are >= 256 MB
+    (place_work_vector; profiles/r02_update_placement.md).  Placement only: the same Lanczos coefficients, bit for bit, with
+    the probe and with EIGENEX_NO_PLACEMENT_PROBE (one process each: the switch is read once), on a 323^3 Laplacian
+    (3.37e7 rows: just above the threshold), one shard, and the probe must have run (stderr lists its candidates)."""
+    import os
+    import subprocess
+    import sys
+
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, '.')
+from cmpt_eigenex_amd import capi
+n = 323
+ctx = capi.Context()
+A = capi.Csr.laplacian3d(ctx, n)
+b = capi.Basis(ctx, A, n ** 3, 7)
+b.upload(capi.VEC_W, np.random.default_rng(8).standard_normal(n ** 3))
+b.lanczos_enqueue(7)
+st, al, be = b.lanczos_state()
+print(' '.join(x.hex() for x in list(al) + list(be)))
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for probe in (True, False):
+        env = dict(os.environ, EIGENEX_DEBUG_POINTERS="1")
+        env.pop("EIGENEX_NO_PLACEMENT_PROBE", None)
+        if not probe:
+            env["EIGENEX_NO_PLACEMENT_PROBE"] = "1"
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[probe] = (r.stdout.strip().splitlines()[-1], r.stderr.count("placement candidate"))
+    assert out[True][0] == out[False][0] and len(out[True][0].split()) == 13
+    assert out[True][1] >= 2 and out[False][1] == 0
