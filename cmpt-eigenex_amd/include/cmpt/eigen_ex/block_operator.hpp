@@ -128,6 +128,22 @@ inline std::shared_ptr<CsrOperator> blockOperator(std::shared_ptr<Context> ctx, 
   return detail_block::upload(std::move(ctx), H, true);
 }
 
+// A dense matrix as a device operator: one sector, one block (the operator of the reference's first sample and of BASELINE config 1
+// is an Eigen dense matrix behind the callback, src/samples/sample_lanczos1.cpp:20-24).  A row's products are added in ascending
+// column order, like the row loop over the CSR form of the same matrix.
+inline std::shared_ptr<CsrOperator> denseOperator(std::shared_ptr<Context> ctx, const DenseMatrix<double>& A) {
+  if (A.rows() != A.cols()) throw LanczosException("a Krylov operator must be square");
+  BlockSparseMatrix<double> H({A.rows()}, {A.cols()});
+  H.addBlock(0, 0, A);
+  return blockOperator(std::move(ctx), H);
+}
+inline std::shared_ptr<CsrOperator> denseOperator(std::shared_ptr<Context> ctx, const DenseMatrix<std::complex<double>>& A) {
+  if (A.rows() != A.cols()) throw LanczosException("a Krylov operator must be square");
+  BlockSparseMatrix<std::complex<double>> H({A.rows()}, {A.cols()});
+  H.addBlock(0, 0, A);
+  return blockOperator(std::move(ctx), H);
+}
+
 inline std::shared_ptr<CsrOperator> csrFromBlocks(std::shared_ptr<Context> ctx, const BlockSparseMatrix<double>& H) {
   if (H.rows() != H.cols()) throw LanczosException("a Krylov operator must be square");
   std::int64_t rb = 0, re = H.rows();

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "cmpt/eigen_ex/arnoldi.hpp"
+#include "cmpt/eigen_ex/block_operator.hpp"
 #include "cmpt/eigen_ex/lanczos.hpp"
 
 int main() {
@@ -46,6 +47,17 @@ int main() {
     std::printf("\"device_operator\": {\"eigenvalues\": [");
     for (Index i = 0; i < dev.eigenvalues().size(); ++i) std::printf("%s%.17g", i ? ", " : "", dev.eigenvalues()[i]);
     std::printf("], \"subspace\": %ld}, ", (long)dev.lanczosvectors().size());
+
+    // the sample's own operator storage: the dense matrix itself on the device (device::denseOperator)
+    DenseMatrix<double> Hd(n, n);
+    for (int r = 0; r < n; ++r)
+      for (int c = 0; c < n; ++c) Hd(r, c) = H[r * n + c];
+    LanczosEigenSolver<double> dense;
+    dense.setDeviceOperator(device::denseOperator(ctx, Hd)).setTolerance(1.0e-5).setMaxIterations(100);
+    dense.compute();
+    std::printf("\"dense_device_operator\": {\"eigenvalues\": [");
+    for (Index i = 0; i < dense.eigenvalues().size(); ++i) std::printf("%s%.17g", i ? ", " : "", dense.eigenvalues()[i]);
+    std::printf("], \"subspace\": %ld}, ", (long)dense.lanczosvectors().size());
 
     // Arnoldi on the same operator: full Krylov space, A P = P D
     ArnoldiEigenSolver<double> ar;

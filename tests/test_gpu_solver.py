@@ -62,8 +62,9 @@ def test_cpp_program_against_reference_sample(golden_dir, tmp_path):
                            "-leigenex_hip", "-Wl,-rpath," + lib])
     out = json.loads(subprocess.check_output([exe]).decode())
     gold = json.load(open(os.path.join(golden_dir, "reference_samples.json")))["sample_lanczos1"]
-    for key in ("host_operator", "device_operator"):
+    for key in ("host_operator", "device_operator", "dense_device_operator"):
         np.testing.assert_allclose(out[key]["eigenvalues"], gold["eigenvalues"], rtol=0, atol=1e-13)
+    assert out["dense_device_operator"] == out["device_operator"]  # same row sums in the same order
     ho = out["host_operator"]
     assert ho["iterations"] == 2 and ho["info"] == 0
     assert ho["log"][-3:] == [
@@ -125,6 +126,47 @@ def test_config1_dense512_lowest5(mods):
         assert 1 - abs(X[:, e] @ ref.eigenvectors[:, e]) < 1e-8
         assert X[np.flatnonzero(X[:, e])[0], e] > 0
     assert es.log()[-2] == "INFO      lanczos steps converged with tolerance"
+
+
+def test_config1_dense512_on_the_device(mods):
+    """BASELINE config 1 with the dense matrix itself as a device operator (one dense block: what device::denseOperator
+    uploads) instead of the host callback: no vector crosses PCIe during the solve.  Same checks as the callback form; the
+    operator adds a row's products in ascending column order (the CSR row loop), numpy's A @ x in BLAS order: compared at
+    rounding level, and bit for bit with the CSR form of the same matrix."""
+    capi, solver = mods
+    n = 512
+    rng = np.random.default_rng(42)
+    R = rng.standard_normal((n, n))
+    A = (R + R.T) / 2
+    init = solver.default_start_vector(n)
+    idx = [0, 1, 2, 3, 4]
+    ref = _oracle_lanczos(lambda x: A @ x, n, init, tolerance=1e-10, indices_for_convergence=idx, max_eigenvalues=5,
+                          max_iterations=600)
+    ctx = capi.Context()
+    D = capi.Csr.upload_blocks(ctx, [n], [n], {(0, 0): A})
+    C = capi.Csr.upload(ctx, n, (n * np.arange(n + 1)).astype(np.int32), np.tile(np.arange(n, dtype=np.int32), n), A.ravel().copy())
+    x = rng.standard_normal(n)
+    ys = []
+    for op in (D, C):
+        b = capi.Basis(ctx, op, n, 2)
+        b.upload(capi.VEC_W, x)
+        b.apply(capi.VEC_W, capi.VEC_V)
+        ys.append(b.download(capi.VEC_V))
+        b.close()
+    np.testing.assert_array_equal(ys[0], ys[1])
+    assert np.abs(ys[0] - A @ x).max() <= 1e-12 * np.abs(A).sum(axis=1).max()
+    es = solver.LanczosEigenSolver()
+    es.setDeviceOperator(D).set(tolerance=1e-10, indicesForConvergence=idx, maxEigenvalues=5, maxIterations=600, initialVector=init)
+    es.compute()
+    r = es.results()
+    scale = abs(ref._tri_vals[0] - ref._tri_vals[-1])
+    assert abs(r["iterations"] - ref.base.iterations) <= 1
+    assert r["neig"] == 5 and r["info_name"] == "Success"
+    np.testing.assert_allclose(r["eigenvalues"], ref.eigenvalues, rtol=0, atol=1e-9 * scale)
+    np.testing.assert_allclose(r["eigenvalues"], np.linalg.eigvalsh(A)[:5], rtol=0, atol=1e-7 * scale)
+    for e in range(5):
+        assert 1 - abs(r["eigenvectors"][:, e] @ ref.eigenvectors[:, e]) < 1e-8
+    ctx.close()
 
 
 @pytest.mark.parametrize("mode", [0, 1])
