@@ -727,10 +727,13 @@ int build_shard_host(eigenex_context_s* c, int64_t n_global, int gshard, const i
     if (column_blocks == -3) {
       for (int wgs : {240, 64, 8, 1})
         if ((want = split_geometry(s.nloc, wgs, 256, &T, &G, max_T))) break;
-    } else if (!exact && split_geometry(s.nloc, 240, 4096, &T, &G, max_T)) {
-      // gathers per 128-byte input line of a tile: >= 3 (real; below that the column-sorted tiles are as good), >= 2 (complex,
-      // where the alternative is column-blocked passes: measured 289 vs 345 us at 2.1 on config 3's pattern with complex values)
-      want = (double)T * (double)s.nnz / (double)s.nloc * (16.0 / es) >= (es == 1 ? 3.0 : 2.0) * (double)(s.nloc + s.nhalo);
+    } else if (!exact) {
+      // Taken whenever the shard is large enough for >= 240 workgroups of >= 4096-row tiles.  The gain does not hinge on many
+      // gathers per input line: measured on uniformly scattered columns (scripts/probe_layouts.py, profiles/r02_layouts.md) the
+      // split tiles beat every other layout from 16 down to 0.3 gathers per line (N = 4e5 .. 1.6e7, 8 .. 64 entries per row), by
+      // 1.3x .. 2.8x over what the automatic mode chose before -- the column order alone keeps the input lines of a group in L2, and
+      // there is neither a row phase nor per-row offsets.
+      want = split_geometry(s.nloc, 240, 4096, &T, &G, max_T);
     }
     SplitLayout L;
     const GlobalOrder order(s);
