@@ -201,14 +201,14 @@ int eigenex_csr_upload_z(eigenex_context_t ctx, int64_t n_global, int64_t row_be
  *                       of a wave gather from shared 128-byte lines, with a 16-bit slot that restores the row order for
  *                       the sums; one launch, slices walked inside the kernel, bit-identical to the row loop.  Needs a
  *                       real operator with 2..64 slices whose rows meet the slices in stored order; error otherwise
- *   column_blocks = -3  split tiles (what the automatic mode takes, ahead of the column-sorted tiles, when a 16384-row tile
- *                       has >= 3 gathers per 128-byte input line): one workgroup per (row tile, column group) adds
+ *   column_blocks = -3  split tiles (what the automatic mode takes, ahead of the column-sorted tiles, for every scattered
+ *                       operator of >= 123,000 rows per shard): one workgroup per (row tile, column group) adds
  *                       column-sorted entries into partial row sums in LDS, a second kernel adds the <= 8 partial sums of a
  *                       row in ascending group order.  The ONLY layout that re-associates a row's sum: y differs from the
  *                       row loop by a few ulp of sum |a_ij x_j| (products are still rounded before they are added), the
  *                       same bits on every run.  1.35x over the column-sorted tiles on BASELINE config 3.  Real and complex
- *                       operators (complex: tiles of 8192 rows, taken automatically from 2 gathers per line; 1.2x over the
- *                       column-blocked passes on config 3's pattern with complex values);
+ *                       operators (complex: tiles of 8192 rows; 1.2x over the column-blocked passes on config 3's pattern
+ *                       with complex values).  1.3x .. 2.8x over the other layouts from N = 4e5 to 1.6e7 (profiles/r02_layouts.md);
  *                       error if a row has thousands of entries in one column group.  Setting the environment variable
  *                       EIGENEX_EXACT_ROW_SUMS keeps the automatic mode to the layouts that are bit-identical to the row loop */
 int eigenex_csr_upload_ex(eigenex_context_t ctx, int64_t n_global, int64_t row_begin, int64_t n_rows,
