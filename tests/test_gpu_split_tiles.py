@@ -249,3 +249,46 @@ def test_split_tiles_complex(capi, shards):
             A.close()
         assert np.abs(H[-3] - H[0]).max() <= 1e-10 * np.abs(H[0]).max()
         ctx.close()
+
+
+def test_heavy_tailed_row_lengths_every_layout_works_or_refuses(capi, cref):
+    """Row lengths from a power law (most rows 1-5 entries, a few with tens of thousands): the automatic choice must produce a
+    correct operator whatever it picks, and each explicit layout either works (bit-identical to the row loop; split tiles:
+    rounding-level) or refuses with an error message -- never a wrong result, never a crash."""
+    rng = np.random.default_rng(2024)
+    n = 300_000
+    counts = np.minimum(rng.zipf(1.6, n), 40_000).astype(np.int64)
+    counts[rng.integers(0, n, 3)] = 60_000  # three rows that alone fill several chunks of every group
+    rowptr = np.zeros(n + 1, np.int64)
+    np.cumsum(counts, out=rowptr[1:])
+    nnz = int(rowptr[-1])
+    assert nnz < 2**31 - 2**20
+    col = rng.integers(0, n, nnz).astype(np.int64)
+    col = col[np.lexsort((col, np.repeat(np.arange(n), counts)))].astype(np.int32)
+    val = rng.uniform(-1, 1, nnz)
+    x = rng.standard_normal(n)
+    rp = rowptr.astype(np.int32)
+    y_ref = cref.csr_spmv(rp, col, val, x, nthreads=4)
+    mag = cref.csr_spmv(rp, col, np.abs(val), np.abs(x), nthreads=4)
+    ctx = capi.Context()
+    seen = {}
+    for K in (None, 0, 3, -2, -3):
+        try:
+            A = capi.Csr.upload(ctx, n, rp, col, val, column_blocks=K)
+        except capi.EigenexError as e:
+            assert K in (-2, -3) and len(str(e)) > 20, (K, str(e))
+            seen[K] = "refused"
+            continue
+        b = capi.Basis(ctx, A, n, 2)
+        b.upload(capi.VEC_W, x)
+        b.apply(capi.VEC_W, capi.VEC_V)
+        y = b.download(capi.VEC_V)
+        seen[K] = A.layout()
+        if A.layout() == "split_tiles":
+            assert np.all(np.abs(y - y_ref) <= 64 * EPS * mag)
+        else:
+            np.testing.assert_array_equal(y, y_ref)
+        b.close()
+        A.close()
+    assert seen[0] == "csr" and seen[3] == "column_blocked" and seen[None] in ("csr", "column_blocked", "sorted_tiles", "split_tiles")
+    ctx.close()
