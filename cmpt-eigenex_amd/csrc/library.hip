@@ -716,9 +716,11 @@ int build_shard_host(eigenex_context_s* c, int64_t n_global, int gshard, const i
   // re-associated.  Column-sorted row tiles (-2: asked for; -1: when eligible): bit-identical to the row loop.  Else
   // column-blocked passes (2..16: asked for).
   // (complex operators: the same conditions on an input of 16-byte elements; split tiles of <= 8192 rows, no sorted tiles)
-  const bool scattered_any = column_blocks == -1 && (s.nloc + s.nhalo) * 8 * es > kSliceBytes && s.nnz / std::max<int64_t>(s.nloc, 1) >= 6 &&
-                             gathers_scattered(s, lcol, lrp);
-  const bool scattered = scattered_any && es == 1;
+  // (rows of >= 3 entries on average for the split tiles -- measured 2x over plain CSR at 4-5 entries per row, N = 2e6 .. 8e6 --
+  // and of >= 6 for the two older layouts, as before)
+  const int64_t mean_row = s.nnz / std::max<int64_t>(s.nloc, 1);
+  const bool scattered_any = column_blocks == -1 && (s.nloc + s.nhalo) * 8 * es > kSliceBytes && mean_row >= 3 && gathers_scattered(s, lcol, lrp);
+  const bool scattered = scattered_any && es == 1 && mean_row >= 6;
   if (column_blocks == -3 || scattered_any) {
     static const bool exact = std::getenv("EIGENEX_EXACT_ROW_SUMS") != nullptr;
     int T = 0, G = 0;
