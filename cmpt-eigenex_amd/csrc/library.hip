@@ -519,6 +519,28 @@ bool gathers_scattered(const CsrShard& s, const std::vector<int32_t>& lcol, cons
   return entries > 0 && 2 * lines >= entries;
 }
 
+// Do the gathers of the plain CSR kernel coalesce?  k_spmv's lane l of a wave loads entries 4l .. 4l+3 of a 256-entry window and
+// gathers them with four instructions: instruction i sees entries 4l+i, l = 0..63.  A stencil's neighbouring rows share input
+// lines (7-point Laplacian: about 10 distinct 128-byte lines per instruction); rows with unrelated columns -- uniformly random,
+// or random inside a band -- give 64 lines per instruction, every gather its own L2 request, and the kernel is bound by the L1s'
+// request rate whatever the L2 hit rate (measured: 2.1 TB/s on a +-20,000-column band that fits L2).  Sampled on every 61st
+// 256-row tile; true when an instruction touches >= 32 distinct lines on average.
+bool gathers_uncoalesced(const CsrShard& s, const std::vector<int32_t>& lcol, const std::vector<int32_t>& lrp) {
+  int64_t instr = 0, lines = 0;
+  int32_t ln[64];
+  for (int64_t r0 = 0; r0 < s.nloc; r0 += 256 * 61) {
+    const int64_t r1 = std::min<int64_t>(r0 + 256, s.nloc);
+    for (int64_t base = lrp[r0] & ~(int64_t)3; base + 256 <= lrp[r1]; base += 256)
+      for (int i = 0; i < 4; ++i) {
+        for (int l = 0; l < 64; ++l) ln[l] = (int32_t)(((int64_t)lcol[(size_t)(base + 4 * l + i)] * s.es) >> 4);
+        std::sort(ln, ln + 64);
+        lines += std::unique(ln, ln + 64) - ln;
+        ++instr;
+      }
+  }
+  return instr > 0 && lines >= 32 * instr;
+}
+
 // Column-sorted row tiles (kernels.hip: k_spmv_sorted).  Eligible when the operator is real, every row meets the slices in
 // stored order (so the result stays bit-identical to the row loop), a (tile, slice) segment fits the LDS product buffer
 // and the slice count stays small.  Returns false (nothing built) otherwise.
@@ -719,8 +741,11 @@ int build_shard_host(eigenex_context_s* c, int64_t n_global, int gshard, const i
   // (rows of >= 3 entries on average for the split tiles -- measured 2x over plain CSR at 4-5 entries per row, N = 2e6 .. 8e6 --
   // and of >= 6 for the two older layouts, as before)
   const int64_t mean_row = s.nnz / std::max<int64_t>(s.nloc, 1);
-  const bool scattered_any = column_blocks == -1 && (s.nloc + s.nhalo) * 8 * es > kSliceBytes && mean_row >= 3 && gathers_scattered(s, lcol, lrp);
-  const bool scattered = scattered_any && es == 1 && mean_row >= 6;
+  // split tiles: whenever the plain kernel's gathers do not coalesce and there is enough work for two launches of ~250 workgroups
+  // (scripts/probe_layouts*.py: also ahead on band matrices whose input window fits L2, 208 against 390 us; behind plain CSR
+  // only on small operators: 2e6 entries, 28 against 17 us)
+  const bool scattered_any = column_blocks == -1 && mean_row >= 3 && s.nnz >= 3000000 && gathers_uncoalesced(s, lcol, lrp);
+  const bool scattered = column_blocks == -1 && es == 1 && (s.nloc + s.nhalo) * 8 > kSliceBytes && mean_row >= 6 && gathers_scattered(s, lcol, lrp);
   if (column_blocks == -3 || scattered_any) {
     static const bool exact = std::getenv("EIGENEX_EXACT_ROW_SUMS") != nullptr;
     int T = 0, G = 0;

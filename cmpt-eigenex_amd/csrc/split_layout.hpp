@@ -4,7 +4,7 @@
 // L2 is bound by the L1s' request rate, and a workgroup needs about as many requests as its row tile touches input LINES.
 // Column-sorted row tiles keep a row's sum in stored order, which forces one workgroup per row tile; 10^6 rows are then 244
 // tiles of 4096 rows = 2 gathers per 128-byte line.  Here a tile has up to 16384 rows (8 gathers per line on BASELINE
-// config 3) and its columns are cut into G groups, one workgroup per (tile, group): every workgroup forms the PARTIAL row sums
+// config 3) and its entries, sorted by column, are cut into G groups of equal count, one workgroup per (tile, group): every workgroup forms the PARTIAL row sums
 // of its group, a second kernel adds the G partial sums of a row in ascending group order.  The row sum is therefore
 // associated differently from the reference's row loop (lanczos.hpp:389 calls a user callback; the row loop is this
 // library's plain-CSR definition): a rounding-level difference, deterministic from run to run.
@@ -58,9 +58,8 @@ bool build_split_layout(int64_t nloc, int64_t ext, const int32_t* lrp, const int
                         int T, int G, SplitLayout& L, int es = 1) {  // es doubles per stored value: 1 real, 2 complex (re, im)
   if (nloc <= 0 || T > kSplitMaxTileRows / es || G < 1 || G > kSplitMaxGroups || ext <= 0 || ext > (int64_t)2147483647 || es < 1 || es > 2) return false;
   const int64_t ntiles = (nloc + T - 1) / T;
-  const int64_t Wg = (ext + G - 1) / G;
   struct Ent {
-    uint32_t pg;   // position inside the group
+    uint32_t pg;   // position of the column in global column order
     uint32_t row;  // row inside the tile
     int32_t src;   // index of the entry in the shard's CSR arrays
   };
@@ -79,34 +78,35 @@ bool build_split_layout(int64_t nloc, int64_t ext, const int32_t* lrp, const int
     const size_t guess = (size_t)((int64_t)lrp[std::min<int64_t>(t1 * T, nloc)] - lrp[std::min<int64_t>(t0 * T, nloc)]);
     P.cp.reserve(guess + guess / 64 + 1024);
     P.val.reserve((guess + guess / 64 + 1024) * (size_t)es);
-    std::vector<std::vector<Ent>> grp((size_t)G);
-    std::vector<Ent> tmp, cur, pending, next_pending;
+    std::vector<Ent> all, tmp, cur, pending, next_pending;
     std::vector<int32_t> stamp((size_t)T, -1);
     int32_t chunk_id = 0;
     for (int64_t t = t0; t < t1; ++t) {
       const int64_t r0 = t * T, r1 = std::min<int64_t>(r0 + T, nloc);
-      for (auto& v : grp) v.clear();
+      // all entries of the tile, sorted by column position (stable LSD radix sort, 11-bit digits: entries arrive in row order and
+      // equal columns keep it), then cut into G groups of EQUAL COUNT: the groups are balanced whatever the structure (a banded
+      // matrix has all the columns of a tile inside a narrow window; equal-width column ranges would leave most groups empty)
+      all.clear();
+      uint32_t maxkey = 0;
       for (int64_t r = r0; r < r1; ++r)
         for (int64_t p = lrp[r]; p < lrp[r + 1]; ++p) {
-          const int64_t pos = order(lcol[p]);
-          const int64_t g = pos / Wg;
-          grp[(size_t)g].push_back(Ent{(uint32_t)(pos - g * Wg), (uint32_t)(r - r0), (int32_t)p});
+          const uint32_t pos = (uint32_t)order(lcol[p]);
+          maxkey = std::max(maxkey, pos);
+          all.push_back(Ent{pos, (uint32_t)(r - r0), (int32_t)p});
         }
+      tmp.resize(all.size());
+      for (int sh = 0; sh < 32 && (sh == 0 || (maxkey >> sh) != 0); sh += 11) {
+        size_t cnt[2049] = {0};
+        for (const Ent& e : all) cnt[((e.pg >> sh) & 2047) + 1]++;
+        for (int d = 0; d < 2048; ++d) cnt[d + 1] += cnt[d];
+        for (const Ent& e : all) tmp[cnt[(e.pg >> sh) & 2047]++] = e;
+        all.swap(tmp);
+      }
       for (int g = 0; g < G; ++g) {
-        auto& v = grp[(size_t)g];
-        // stable LSD radix sort by position (11-bit digits): entries arrive in row order, equal columns keep it
-        uint32_t maxkey = 0;
-        for (const Ent& e : v) maxkey = std::max(maxkey, e.pg);
-        tmp.resize(v.size());
-        for (int sh = 0; sh < 32 && (sh == 0 || (maxkey >> sh) != 0); sh += 11) {
-          size_t cnt[2049] = {0};
-          for (const Ent& e : v) cnt[((e.pg >> sh) & 2047) + 1]++;
-          for (int d = 0; d < 2048; ++d) cnt[d + 1] += cnt[d];
-          for (const Ent& e : v) tmp[cnt[(e.pg >> sh) & 2047]++] = e;
-          v.swap(tmp);
-        }
+        const size_t g_lo = all.size() * (size_t)g / (size_t)G, g_hi = all.size() * (size_t)(g + 1) / (size_t)G;
+        const Ent* v = all.data() + g_lo;
         P.wg_first.push_back((int32_t)(P.chunk.size() / 4));
-        const size_t n = v.size();
+        const size_t n = g_hi - g_lo;
         const size_t max_chunks = 2 * (n / (size_t)std::min(kSplitChunk, T)) + 64;  // a chunk holds a row at most once: <= T entries
         size_t i = 0, made = 0;
         pending.clear();
@@ -130,7 +130,9 @@ bool build_split_layout(int64_t nloc, int64_t ext, const int32_t* lrp, const int
           };
           for (const Ent& e : pending)  // deferred entries first: they have the lowest columns
             if (!place(e)) next_pending.push_back(e);
-          while (i < n && (int)cur.size() < kSplitChunk && next_pending.size() < (size_t)kSplitChunk) {
+          // (the deferred list may grow to 32 chunks' worth: a run of rows that each have many entries at neighbouring columns --
+          // e.g. 16 stored entries of every row in one column -- is then dealt out one entry per row and chunk, full chunks each)
+          while (i < n && (int)cur.size() < kSplitChunk && next_pending.size() < (size_t)32 * kSplitChunk) {
             const Ent& e = v[i];
             if (!cur.empty() && e.pg - first >= (1u << kSplitRelBits)) break;
             if (!place(e)) next_pending.push_back(e);
@@ -139,7 +141,7 @@ bool build_split_layout(int64_t nloc, int64_t ext, const int32_t* lrp, const int
           pending.swap(next_pending);
           // emit: full blocks of 256 transposed (stored[4*lane + j] = sorted[64*j + lane]: the lanes of one gather instruction
           // see consecutive sorted entries, a lane's four entries come with one 16-byte load), the rest as it is
-          const int64_t pos0 = (int64_t)g * Wg + first;
+          const int64_t pos0 = (int64_t)first;
           P.chunk.push_back((int32_t)P.cp.size());
           P.chunk.push_back((int32_t)(P.cp.size() + cur.size()));
           P.chunk.push_back((int32_t)pos0);

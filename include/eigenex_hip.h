@@ -201,8 +201,9 @@ int eigenex_csr_upload_z(eigenex_context_t ctx, int64_t n_global, int64_t row_be
  *                       of a wave gather from shared 128-byte lines, with a 16-bit slot that restores the row order for
  *                       the sums; one launch, slices walked inside the kernel, bit-identical to the row loop.  Needs a
  *                       real operator with 2..64 slices whose rows meet the slices in stored order; error otherwise
- *   column_blocks = -3  split tiles (what the automatic mode takes, ahead of the column-sorted tiles, for every scattered
- *                       operator of >= 123,000 rows per shard): one workgroup per (row tile, column group) adds
+ *   column_blocks = -3  split tiles (what the automatic mode takes, ahead of the column-sorted tiles, for every operator of
+ *                       >= 123,000 rows per shard and >= 3e6 entries whose gathers would not coalesce in the plain kernel --
+ *                       uniformly random columns, random columns inside a band, ...): one workgroup per (row tile, column group) adds
  *                       column-sorted entries into partial row sums in LDS, a second kernel adds the <= 8 partial sums of a
  *                       row in ascending group order.  The ONLY layout that re-associates a row's sum: y differs from the
  *                       row loop by a few ulp of sum |a_ij x_j| (products are still rounded before they are added), the

@@ -42,10 +42,14 @@ static int one_case(int64_t n, int top, int heavy, int heavy_len, int T, int G, 
   if (L.ntiles != ntiles || (int64_t)L.wg_chunk.size() != ntiles * G + 1) return fail("workgroup table", L.ntiles, (long)L.wg_chunk.size());
   std::vector<double> y((size_t)n, 0.0), part((size_t)G * n, 0.0);
   std::vector<int> seen((size_t)T, -1);
-  size_t used = 0;
+  size_t used = 0, tile_entries = 0;
+  int64_t prev_group_max = -1, group_max = -1;
   int chunk_serial = 0;
   for (int64_t wg = 0; wg < ntiles * G; ++wg) {
     const int64_t tile = wg / G, g = wg % G;
+    if (g == 0) prev_group_max = -1, group_max = -1, tile_entries = 0;
+    else prev_group_max = group_max;
+    const size_t used_before = used;
     std::vector<double> acc((size_t)T, 0.0);
     if (L.wg_chunk[(size_t)wg] > L.wg_chunk[(size_t)wg + 1]) return fail("chunk ranges not ascending", wg);
     for (int32_t c = L.wg_chunk[(size_t)wg]; c < L.wg_chunk[(size_t)wg + 1]; ++c, ++chunk_serial) {
@@ -59,7 +63,9 @@ static int one_case(int64_t n, int top, int heavy, int heavy_len, int T, int G, 
         if (seen[row] == chunk_serial) return fail("a row twice in one chunk", row, c);
         seen[row] = chunk_serial;
         const int64_t pos = (int64_t)pos0 + rel;
-        if (pos < 0 || pos >= ext || pos / ((ext + G - 1) / G) != g) return fail("column outside its group", (long)pos, (long)g);
+        if (pos < 0 || pos >= ext) return fail("column out of range", (long)pos, (long)g);
+        if (pos < prev_group_max) return fail("groups of a tile overlap in column order", (long)pos, (long)g);  // groups = consecutive parts of the sorted tile
+        group_max = std::max(group_max, pos);
         // within a full transposed block, storage index 4*lane + j holds sorted[64*j + lane]: ascending along lanes for fixed j
         const int32_t off = q - e0, blk = off / 256, in = off % 256;
         if ((int64_t)(blk + 1) * 256 <= e1 - e0 && in >= 4) {
@@ -72,6 +78,15 @@ static int one_case(int64_t n, int top, int heavy, int heavy_len, int T, int G, 
       }
     }
     for (int64_t i = 0; i < T && tile * T + i < n; ++i) part[(size_t)g * n + tile * T + i] = acc[(size_t)i];
+    // equal counts: the groups of a tile differ by at most one entry
+    const size_t mine = used - used_before;
+    tile_entries += mine;
+    if (g == G - 1) {
+      const int64_t tile_rows_end = std::min<int64_t>((tile + 1) * T, n);
+      const size_t expect = (size_t)(rp[(size_t)tile_rows_end] - rp[(size_t)(tile * T)]);
+      if (tile_entries != expect) return fail("entries of a tile", (long)tile_entries, (long)expect);
+    }
+    if (mine > (size_t)(rp[(size_t)std::min<int64_t>((tile + 1) * T, n)] - rp[(size_t)(tile * T)]) / (size_t)G + 1) return fail("group larger than its share", (long)mine, (long)g);
   }
   if (used != val.size()) return fail("entries used", (long)used, (long)val.size());
   for (int64_t r = 0; r < n; ++r) {
@@ -97,6 +112,29 @@ int main() {
   rc |= one_case(20000, 12, 0, 0, 16384, 8, 0, 3);       // one full tile and a partial one
   rc |= one_case(5000, 40, 50, 60, 1024, 1, 77, 4);       // one group: the entries of a 60-entry row go to 60 different chunks
   rc |= one_case(300, 3, 0, 0, 256, 8, 0, 5);             // nearly empty groups
+  {  // a band with clipped columns: the first rows hold many stored entries in column 0 each, the tile's columns fill a narrow
+     // window -- groups of equal count stay balanced, the deferred entries are dealt out in full chunks
+    const int64_t n = 40000, half = 6000;
+    const int per = 24;
+    std::mt19937_64 rng(11);
+    std::vector<int32_t> rp((size_t)n + 1, 0), col;
+    std::vector<double> val, x((size_t)n);
+    for (int64_t r = 0; r < n; ++r) {
+      std::vector<int32_t> c((size_t)per);
+      for (auto& v : c) v = (int32_t)std::min<int64_t>(std::max<int64_t>(r + (int64_t)(rng() % (uint64_t)(2 * half + 1)) - half, 0), n - 1);
+      std::sort(c.begin(), c.end());
+      for (int32_t v : c) col.push_back(v), val.push_back((double)((int)(rng() % 9) - 4));
+      rp[(size_t)r + 1] = (int32_t)col.size();
+    }
+    SplitLayout L;
+    auto ident = [](int64_t lc) { return lc; };
+    if (!build_split_layout(n, n, rp.data(), col.data(), val.data(), ident, 16384, 2, L)) rc |= fail("banded matrix with clipped columns refused");
+    else {
+      const size_t nch = L.chunk.size() / 4 - 2;
+      if (nch > 2 * (col.size() / kSplitChunk) + 16) rc |= fail("banded matrix: chunks far from full", (long)nch, (long)(col.size() / kSplitChunk));
+      std::printf("ok: banded n=%ld chunks=%zu for %zu entries\n", (long)n, nch, col.size());
+    }
+  }
   {  // a dense row: one chunk per entry would be needed -> the builder refuses
     const int64_t n = 3000;
     std::vector<int32_t> rp((size_t)n + 1, 0), col;
