@@ -292,3 +292,56 @@ def test_heavy_tailed_row_lengths_every_layout_works_or_refuses(capi, cref):
         A.close()
     assert seen[0] == "csr" and seen[3] == "column_blocked" and seen[None] in ("csr", "column_blocked", "sorted_tiles", "split_tiles")
     ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(14))
+def test_split_tiles_structure_fuzz(capi, cref, seed):
+    """Seeded structures through the forced split-tile layout with integer-valued data (exact under any association, so the
+    output must equal the row loop bit for bit): uniform columns, columns inside a band (clipped at the borders: many stored
+    entries of a row in one column), clustered columns, duplicate entries, empty rows, a few long rows; 1-4 loopback shards;
+    sizes from a handful of rows to several tiles.  A refusal is allowed only with the documented message."""
+    rng = np.random.default_rng(5150 + seed)
+    n = int(rng.choice([7, 300, 5_000, 20_001, 60_000]))
+    kind = ["uniform", "band", "cluster", "mixed"][seed % 4]
+    top = int(rng.choice([4, 12, 40]))
+    counts = rng.integers(0, top + 1, n)
+    counts[rng.integers(0, n, max(1, n // 40))] = 0
+    if n > 1000:
+        counts[rng.integers(0, n, 3)] = int(rng.choice([200, 1500]))
+    rows = np.repeat(np.arange(n), counts)
+    nnz = rows.size
+    if kind == "uniform":
+        col = rng.integers(0, n, nnz)
+    elif kind == "band":
+        half = max(2, n // int(rng.choice([4, 50])))
+        col = np.clip(rows + rng.integers(-half, half + 1, nnz), 0, n - 1)
+    elif kind == "cluster":
+        centres = rng.integers(0, n, 8)
+        col = np.clip(centres[rng.integers(0, 8, nnz)] + rng.integers(-20, 21, nnz), 0, n - 1)
+    else:
+        col = np.where(rng.random(nnz) < 0.5, rng.integers(0, n, nnz), np.clip(rows + rng.integers(-3, 4, nnz), 0, n - 1))
+    order = np.lexsort((col, rows))
+    col = col[order].astype(np.int32)
+    rowptr = np.zeros(n + 1, np.int64)
+    np.cumsum(counts, out=rowptr[1:])
+    rowptr = rowptr.astype(np.int32)
+    val = rng.integers(-8, 9, nnz).astype(float)
+    x = rng.integers(-4, 5, n).astype(float)
+    y_ref = cref.csr_spmv(rowptr, col, val, x, nthreads=2)
+    shards = int(rng.choice([1, 1, 2, 3, 4]))
+    ctx = capi.Context(loopback_shards=shards) if shards > 1 else capi.Context()
+    try:
+        A = capi.Csr.upload(ctx, n, rowptr, col, val, column_blocks=-3)
+    except capi.EigenexError as e:
+        assert "split tiles" in str(e), str(e)
+        ctx.close()
+        return
+    assert A.layout() == "split_tiles"
+    b = capi.Basis(ctx, A, n, 2)
+    b.upload(capi.VEC_W, x)
+    dot = b.apply(capi.VEC_W, capi.VEC_V, 0.0, want_dot=True)
+    np.testing.assert_array_equal(b.download(capi.VEC_V), y_ref)
+    assert dot == float(x @ y_ref)
+    b.apply(capi.VEC_W, capi.VEC_V, -2.0)
+    np.testing.assert_array_equal(b.download(capi.VEC_V), y_ref - 2.0 * x)
+    ctx.close()
