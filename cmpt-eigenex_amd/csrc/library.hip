@@ -760,7 +760,9 @@ int build_shard_host(eigenex_context_s* c, int64_t n_global, int gshard, const i
       // split tiles beat every other layout from 16 down to 0.3 gathers per line (N = 4e5 .. 1.6e7, 8 .. 64 entries per row), by
       // 1.3x .. 2.8x over what the automatic mode chose before -- the column order alone keeps the input lines of a group in L2, and
       // there is neither a row phase nor per-row offsets.
-      want = split_geometry(s.nloc, 240, 4096, &T, &G, max_T);
+      // (long rows -- >= 48 entries on average -- also on small shards, with tiles down to 256 rows: the plain kernel adds a row's
+      // products one after the other in its row phase, 30,000 rows x 256 entries: 427 us against 57 us here)
+      want = split_geometry(s.nloc, 240, mean_row >= 48 ? 256 : 4096, &T, &G, max_T);
     }
     SplitLayout L;
     const GlobalOrder order(s);
