@@ -460,6 +460,9 @@ __device__ __forceinline__ void arnoldi_begin_record(const InlineArnoldiBegin& a
   ab.ctrl->scale = scale;
 }
 
+// LONG_ROWS: the row phase reads sixteen products at a time (operators with >= 16 entries per row on average; the short-row form
+// is kept as it was: the same loop in the long-row kernel costs the 7-point stencil 1.8 % through its register allocation)
+template <bool LONG_ROWS>
 __global__ __launch_bounds__(kBlock) void k_spmv(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                  const double* __restrict__ val, const double* __restrict__ x_ext,
                                                  const double* __restrict__ scale_ptr, double shift,
@@ -567,7 +570,18 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int32_t* __restrict__ row
       // phase 2: stored order, multiply-then-add
       const int lo = rs > cb ? rs : cb;
       const int hi = re < cend ? re : cend;
-      for (int p = lo; p < hi; ++p) sum = sum + prod[skew(p - cb)];
+      int p = lo;
+      // long rows: sixteen LDS reads in flight, then the sixteen adds in stored order (a row of 256 entries spent its time waiting
+      // for one read after the other: 413 -> 156 us at 30,000 rows x 256 contiguous columns, 41 -> 25 us at 100,000 x 64); rows
+      // shorter than 16 entries in the chunk -- the stencils -- take the plain loop below as before
+      for (; LONG_ROWS && p + 16 <= hi; p += 16) {
+        double t[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t[i] = prod[skew(p + i - cb)];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sum = sum + t[i];
+      }
+      for (; p < hi; ++p) sum = sum + prod[skew(p - cb)];
       __syncthreads();
     }
     if ((pass & kPassNotLast) && r < n) {
@@ -1759,8 +1773,12 @@ void launch_spmv(hipStream_t s, const int32_t* rowptr, const int32_t* col, const
   const int64_t ntiles = (n + kSpmvRows - 1) / kSpmvRows;
   const InlineFin nofin{nullptr, 0, 0, 0.0, nullptr, nullptr, nullptr};
   const InlineArnoldiBegin nobegin{nullptr, 0.0, 0, 0, nullptr, 0, 0};
-  hipLaunchKernelGGL(k_spmv, dim3(grid), dim3(kBlock), 0, s, rowptr, col, val, x_ext, scale, shift, y, u_out, n,
-                     ntiles, partials, spmv_flags, pass, ctrl, fin ? *fin : nofin, begin ? *begin : nobegin);
+  if (spmv_flags & 4)  // bit 2: long rows
+    hipLaunchKernelGGL(k_spmv<true>, dim3(grid), dim3(kBlock), 0, s, rowptr, col, val, x_ext, scale, shift, y, u_out, n,
+                       ntiles, partials, spmv_flags, pass, ctrl, fin ? *fin : nofin, begin ? *begin : nobegin);
+  else
+    hipLaunchKernelGGL(k_spmv<false>, dim3(grid), dim3(kBlock), 0, s, rowptr, col, val, x_ext, scale, shift, y, u_out, n,
+                       ntiles, partials, spmv_flags, pass, ctrl, fin ? *fin : nofin, begin ? *begin : nobegin);
 }
 
 void launch_spmv_sorted(hipStream_t s, const SortedOperatorView& op, const double* x_ext, const double* scale, double shift, double* y,

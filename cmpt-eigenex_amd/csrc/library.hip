@@ -1336,8 +1336,8 @@ void launch_operator(hipStream_t st, const CsrShard* m, int es, const double* x_
       launch_spmv_z(st, rp, m->col, m->val, x_ext, scale, shift, shift_im, y, u_out, m->nloc, last ? partials : nullptr, pstride,
                     grid, ctrl, flags, pass);
     else
-      launch_spmv(st, rp, m->col, m->val, x_ext, scale, shift, y, u_out, m->nloc, last ? partials : nullptr, grid, ctrl, flags,
-                  pass, nullptr, m->passes == 1 ? begin : nullptr);
+      launch_spmv(st, rp, m->col, m->val, x_ext, scale, shift, y, u_out, m->nloc, last ? partials : nullptr, grid, ctrl,
+                  flags | (m->nnz >= 16 * m->nloc ? 4 : 0), pass, nullptr, m->passes == 1 ? begin : nullptr);
   }
 }
 
@@ -1510,7 +1510,7 @@ int lanczos_step_inline(eigenex_basis_s* b, int k, int first, int stride, int co
     InlineFin fn{s.pnorm, s.g_vec, kFinLanczos, b->threshold, s.beta, s.ctrl, s.hbuf + b->slot_nrm()};
     ProfScope ps(c, EIGENEX_K_SPMV, 12.0 * m->nnz + 4.0 * (m->nloc + 1) + 32.0 * s.nd + 16.0 * s.nd);
     launch_spmv(st, m->rowptr, m->col, m->val, s.w, nullptr, b->shift, s.v, s.V + (int64_t)(k + 1) * s.ldd, m->nloc, s.palpha, s.g_spmv, s.ctrl,
-                s.spmv_flags, 0, &fn);
+                s.spmv_flags | (m->nnz >= 16 * m->nloc ? 4 : 0), 0, &fn);
   }
   if (last_in_batch) {
     ProfScope ps(c, EIGENEX_K_SMALL, 0.0);
