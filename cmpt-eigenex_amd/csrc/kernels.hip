@@ -1006,6 +1006,7 @@ __global__ __launch_bounds__(kBlock) void k_split_combine_z(const double2* __res
   }
 }
 
+template <bool LONG_ROWS>  // as for k_spmv: eight (re, im) products read before they are added, for operators with long rows
 __global__ __launch_bounds__(kBlock) void k_spmv_z(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                    const double2* __restrict__ val, const double2* __restrict__ x_ext,
                                                    const double* __restrict__ scale_ptr, double shift_re,
@@ -1051,7 +1052,18 @@ __global__ __launch_bounds__(kBlock) void k_spmv_z(const int32_t* __restrict__ r
       __syncthreads();
       const int lo = rs > cb ? rs : cb;
       const int hi = re < cend ? re : cend;
-      for (int p = lo; p < hi; ++p) {
+      int p = lo;
+      for (; LONG_ROWS && p + 8 <= hi; p += 8) {
+        double2 t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = prod[skewz(p + i - cb)];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          sum.x = sum.x + t[i].x;
+          sum.y = sum.y + t[i].y;
+        }
+      }
+      for (; p < hi; ++p) {
         const double2 t = prod[skewz(p - cb)];
         sum.x = sum.x + t.x;
         sum.y = sum.y + t.y;
@@ -1750,9 +1762,14 @@ void launch_spmv_z(hipStream_t s, const int32_t* rowptr, const int32_t* col, con
                    const double* scale, double shift_re, double shift_im, double* y, double* u_out, int64_t n,
                    double* partials, int pstride, int grid, const Ctrl* ctrl, int spmv_flags, int pass) {
   const int64_t ntiles = (n + kSpmvRows - 1) / kSpmvRows;
-  hipLaunchKernelGGL(k_spmv_z, dim3(grid), dim3(kBlock), 0, s, rowptr, col, reinterpret_cast<const double2*>(val),
-                     reinterpret_cast<const double2*>(x_ext), scale, shift_re, shift_im, reinterpret_cast<double2*>(y),
-                     reinterpret_cast<double2*>(u_out), n, ntiles, partials, pstride, spmv_flags, pass, ctrl);
+  if (spmv_flags & 4)  // bit 2: long rows
+    hipLaunchKernelGGL(k_spmv_z<true>, dim3(grid), dim3(kBlock), 0, s, rowptr, col, reinterpret_cast<const double2*>(val),
+                       reinterpret_cast<const double2*>(x_ext), scale, shift_re, shift_im, reinterpret_cast<double2*>(y),
+                       reinterpret_cast<double2*>(u_out), n, ntiles, partials, pstride, spmv_flags, pass, ctrl);
+  else
+    hipLaunchKernelGGL(k_spmv_z<false>, dim3(grid), dim3(kBlock), 0, s, rowptr, col, reinterpret_cast<const double2*>(val),
+                       reinterpret_cast<const double2*>(x_ext), scale, shift_re, shift_im, reinterpret_cast<double2*>(y),
+                       reinterpret_cast<double2*>(u_out), n, ntiles, partials, pstride, spmv_flags, pass, ctrl);
 }
 
 void launch_shift_dot_z(hipStream_t s, double* y, const double* u, double shift_re, double shift_im, int64_t n,

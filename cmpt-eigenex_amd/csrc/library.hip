@@ -1334,7 +1334,7 @@ void launch_operator(hipStream_t st, const CsrShard* m, int es, const double* x_
     const int32_t* rp = m->rowptr + (int64_t)k * (m->nloc + 1);
     if (es == 2)
       launch_spmv_z(st, rp, m->col, m->val, x_ext, scale, shift, shift_im, y, u_out, m->nloc, last ? partials : nullptr, pstride,
-                    grid, ctrl, flags, pass);
+                    grid, ctrl, flags | (m->nnz >= 16 * m->nloc ? 4 : 0), pass);
     else
       launch_spmv(st, rp, m->col, m->val, x_ext, scale, shift, y, u_out, m->nloc, last ? partials : nullptr, grid, ctrl,
                   flags | (m->nnz >= 16 * m->nloc ? 4 : 0), pass, nullptr, m->passes == 1 ? begin : nullptr);
