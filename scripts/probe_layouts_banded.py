@@ -1,3 +1,6 @@
+"""Operator layouts on matrices whose columns are random INSIDE A BAND around the diagonal (clipped at the borders): microseconds per
+application for plain CSR (0), forced split tiles (-3) and the automatic choice (-1).  Numbers in profiles/r02_layouts.md.
+usage: python scripts/probe_layouts_banded.py"""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np

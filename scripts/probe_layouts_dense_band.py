@@ -1,3 +1,6 @@
+"""Operator layouts on rows of CONSECUTIVE columns (a dense band: the plain kernel's gathers coalesce, rows are long): plain CSR (0), forced
+split tiles (-3), automatic (-1).  Shows the long-row form of k_spmv's row phase.  Numbers in profiles/r02_layouts.md.
+usage: python scripts/probe_layouts_dense_band.py"""
 import sys
 sys.path.insert(0, ".")
 import numpy as np
