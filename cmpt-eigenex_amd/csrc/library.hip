@@ -2554,7 +2554,9 @@ int eigenex_basis_create_ex(eigenex_context_t c, eigenex_csr_t csr, int64_t n_gl
       HIPCHK(hipMalloc(&s.w, sizeof(double) * (size_t)(s.ldv + s.nhalo + 8) * s.es));
       HIPCHK(hipMemsetAsync(s.w, 0, sizeof(double) * (size_t)(s.ldv + s.nhalo + 8) * s.es, c->stream));
       s.g_vec = grid_for_tiles((s.nd + kTileRows - 1) / kTileRows, kDefaultVecBlocksPerCu);
-      s.g_spmv = (s.csr && s.csr->split) ? split_combine_grid(s.nloc) : (s.csr && s.csr->sorted) ? sorted_grid(s.nloc, s.csr->tile_rows) : grid_for_tiles((s.nloc + kSpmvRows - 1) / kSpmvRows, kDefaultSpmvBlocksPerCu);
+      s.g_spmv = (s.csr && s.csr->split) ? split_combine_grid(s.nloc) : (s.csr && s.csr->sorted) ? sorted_grid(s.nloc, s.csr->tile_rows) : grid_for_tiles((s.nloc + kSpmvRows - 1) / kSpmvRows,
+                                                         // long rows: 8 workgroups per CU measured 7-8 % ahead of 4 (scripts/probe_spmv_flags.py); the stencils: equal
+                                                         (s.csr && s.csr->nnz >= 16 * s.csr->nloc) ? 2 * kDefaultSpmvBlocksPerCu : kDefaultSpmvBlocksPerCu);  // (dense blocks the same: the CSR and the block form of one matrix then sum their alpha partials alike)
       // room for eigenex_basis_tune up to kMaxBlocksPerCu workgroups per CU
       s.pstride = std::max(grid_for_tiles((s.nd + kTileRows - 1) / kTileRows, kMaxBlocksPerCu),
                            grid_for_tiles((s.nloc + kSpmvRows - 1) / kSpmvRows, kMaxBlocksPerCu));
