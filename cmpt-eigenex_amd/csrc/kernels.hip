@@ -412,7 +412,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce(const double* __restrict__ pa
 // Epilogue fuses the shift, the store of the scaled input into the basis slab
 // and the partial dot alpha = u.v.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ int skew(int i) { return i + (i >> 5); }
+// skew(), the chunk / lane / row-window arithmetic: spmv_index.hpp (the host replay tests/cpp/spmv_replay_host.cpp runs the same functions)
 
 // once-read streams (val/col): non-temporal 16-byte loads, so that they do not displace the operator
 // input x from L2 / Infinity Cache
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int32_t* __restrict__ row
                                                  double* __restrict__ y, double* __restrict__ u_out, int64_t n,
                                                  int64_t ntiles, double* __restrict__ partials, int spmv_flags,
                                                  int pass, const Ctrl* ctrl, InlineFin fin, InlineArnoldiBegin ab) {  // no __restrict__ on ctrl: fin.ctrl / ab.ctrl alias it
-  __shared__ double prod[kSpmvChunk + kSpmvChunk / 32 + 8];
+  __shared__ double prod[kSpmvProdSlots];
   __shared__ double lds4[4];
   if (ctrl->stopped) return;
   double scale = (scale_ptr && !ab.ctrl) ? *scale_ptr : 1.0;
@@ -514,15 +514,16 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int32_t* __restrict__ row
     const int64_t r = tile * kSpmvRows + tid;
     int nrs, nre, np0, np1;
     tile_rows(tile + tr.step, nrs, nre, np0, np1);
-    const int pa = p0 & ~3;  // aligned start: int4 / double2 loads
+    const int pa = spmv_aligned_start(p0);  // int4 / double2 loads
     double sum = ((pass & kPassCarry) && r < n) ? y[r] : 0.0;  // column-blocked: carry the row sum from pass to pass
     for (int cb = pa; cb < p1; cb += kSpmvChunk) {
-      const int cend = (cb + kSpmvChunk < p1) ? cb + kSpmvChunk : p1;
+      const int cend = spmv_chunk_end(cb, p1);
       // phase 1: a chunk is two rounds of 4 entries per lane; all six 16-byte loads are issued before
       // the first use, then the eight gathers.  Entries outside [p0, p1) are valid neighbours' entries
       // or the zero padding behind nnz; their products are written but never read.
-      const int q0 = cb + 4 * tid, q1 = q0 + 4 * kBlock;
-      const bool in0 = q0 < cend, in1 = q1 < cend;
+      const SpmvLaneLoads ll = spmv_lane_loads(cb, cend, tid);
+      const int q0 = ll.q0, q1 = ll.q1;
+      const bool in0 = ll.in0, in1 = ll.in1;
       int4 ca = make_int4(0, 0, 0, 0), cbv = make_int4(0, 0, 0, 0);
       double2 a01 = make_double2(0.0, 0.0), a23 = a01, b01 = a01, b23 = a01;
       if (nt) {  // wave-uniform
@@ -568,8 +569,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int32_t* __restrict__ row
       }
       __syncthreads();
       // phase 2: stored order, multiply-then-add
-      const int lo = rs > cb ? rs : cb;
-      const int hi = re < cend ? re : cend;
+      int lo, hi;
+      spmv_row_window(rs, re, cb, cend, &lo, &hi);
       int p = lo;
       // long rows: sixteen LDS reads in flight, then the sixteen adds in stored order (a row of 256 entries spent its time waiting
       // for one read after the other: 413 -> 156 us at 30,000 rows x 256 contiguous columns, 41 -> 25 us at 100,000 x 64); rows
@@ -882,8 +883,6 @@ __global__ __launch_bounds__(kBlock) void k_split_combine(const double* __restri
 // stored-order accumulation; products use separate multiplies and adds (no contraction),
 // like a plain C complex multiply.  shift is complex (ArnoldiBase::eigenvalueShift_ is a
 // Scalar, arnoldi.hpp:108); partials hold (re, im) of conj(u).y.
-constexpr int kSpmvChunkZ = 1024;
-__device__ __forceinline__ int skewz(int i) { return i + (i >> 4); }
 
 __device__ __forceinline__ double2 cmul_nofma(double2 a, double2 b) {
 #pragma clang fp contract(off)
@@ -1014,7 +1013,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv_z(const int32_t* __restrict__ r
                                                    double2* __restrict__ u_out, int64_t n, int64_t ntiles,
                                                    double* __restrict__ partials, int pstride, int spmv_flags,
                                                    int pass, const Ctrl* __restrict__ ctrl) {
-  __shared__ double2 prod[kSpmvChunkZ + kSpmvChunkZ / 16 + 8];
+  __shared__ double2 prod[kSpmvProdSlotsZ];
   __shared__ double lds4[4];
   if (ctrl->stopped) return;
   const double scale = scale_ptr ? *scale_ptr : 1.0;
@@ -1033,10 +1032,10 @@ __global__ __launch_bounds__(kBlock) void k_spmv_z(const int32_t* __restrict__ r
     const int64_t rend = (r0 + kSpmvRows < n) ? r0 + kSpmvRows : n;
     const int p0 = rowptr[r0];
     const int p1 = rowptr[rend];
-    const int pa = p0 & ~3;
+    const int pa = spmv_aligned_start(p0);
     double2 sum = ((pass & kPassCarry) && r < n) ? y[r] : make_double2(0.0, 0.0);
     for (int cb = pa; cb < p1; cb += kSpmvChunkZ) {
-      const int cend = (cb + kSpmvChunkZ < p1) ? cb + kSpmvChunkZ : p1;
+      const int cend = spmv_chunk_end(cb, p1, kSpmvChunkZ);
       for (int q = cb + 4 * tid; q < cend; q += 4 * kBlock) {
         const int4 c4 = *reinterpret_cast<const int4*>(col + q);
         const double2 v0 = val[q], v1 = val[q + 1], v2 = val[q + 2], v3 = val[q + 3];

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "split_layout.hpp"
+#include "spmv_index.hpp"
 
 namespace eigenex {
 
@@ -22,11 +23,9 @@ struct Ctrl {
   double residue;  // Arnoldi residue_
 };
 
-constexpr int kBlock = 256;          // threads per workgroup (4 wave64)
+// kBlock (256 threads = 4 wave64), kSpmvRows, kSpmvChunk: spmv_index.hpp (shared with the host replay of k_spmv)
 constexpr int kRowsPerThread = 8;    // vector kernels: 4 x double2 per thread per column
 constexpr int kTileRows = kBlock * kRowsPerThread;  // 2048 rows per tile
-constexpr int kSpmvRows = 256;       // SpMV: rows per tile (one row per thread in the row phase)
-constexpr int kSpmvChunk = 2048;     // SpMV: products staged in LDS per chunk
 
 struct ColumnSet {     // which vectors a dots/update pass runs over, in reference order
   const double* V;     // basis slab, column c at V + c*ldv

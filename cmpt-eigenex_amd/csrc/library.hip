@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/eigenex_hip.h"
+#include "csr_passes.hpp"
 #include "kernels.hpp"
 
 using namespace eigenex;
@@ -426,60 +427,15 @@ int finish_send(eigenex_context_s* c, CsrShard& s, const std::vector<int32_t>& i
 }
 
 // Host-side shard construction from user CSR arrays (global columns).
-// Column blocking (include/eigenex_hip.h, eigenex_csr_upload_ex).  Slices are cut in GLOBAL column order --
-// halo columns below the shard, local columns, halo columns above -- so that a row with ascending global
-// columns meets them in pass order.  Returns the number of passes and fills blk[p] (pass of stored entry p).
-constexpr int kMaxColumnBlocks = 16;
-constexpr int64_t kSliceBytes = 2 << 20;  // half of one XCD's 4 MB L2: the rest is left to the val/col streams
-
+// Column blocking (include/eigenex_hip.h, eigenex_csr_upload_ex): csr_passes.hpp -- choose_column_blocks (pass of every stored
+// entry) and group_entries_by_pass (the arrays k_spmv walks), shared with the host replay tests/cpp/spmv_replay_host.cpp.
+int64_t halo_below(const CsrShard& s) {
+  return std::lower_bound(s.halo_cols.begin(), s.halo_cols.end(), (int32_t)std::min<int64_t>(s.rb, 2147483647)) - s.halo_cols.begin();
+}
 int choose_column_blocks(const CsrShard& s, const std::vector<int32_t>& lcol, const std::vector<int32_t>& lrp, int request,
                          std::vector<uint8_t>& blk) {
-  if (request == 0 || request == 1 || s.nnz == 0 || s.nloc == 0) return 1;
-  const int64_t ext = s.nloc + s.nhalo;
-  int K = request;
-  if (request < 0) {
-    const int64_t need = (ext * 8 * s.es + kSliceBytes - 1) / kSliceBytes;
-    const int64_t avg = s.nnz / s.nloc;
-    K = (int)std::min<int64_t>(std::min<int64_t>(need, avg / 6), 8);
-    if (K < 2) return 1;
-    // scattered gathers?  sample row tiles: distinct 128-byte lines of the operator input per stored entry
-    int64_t entries = 0, lines = 0;
-    std::vector<int32_t> tmp;
-    for (int64_t r0 = 0; r0 < s.nloc; r0 += 256 * 61) {
-      const int64_t r1 = std::min<int64_t>(r0 + 256, s.nloc);
-      tmp.assign(lcol.begin() + lrp[r0], lcol.begin() + lrp[r1]);
-      for (auto& x : tmp) x = (int32_t)(((int64_t)x * s.es) >> 4);
-      std::sort(tmp.begin(), tmp.end());
-      entries += (int64_t)tmp.size();
-      lines += std::unique(tmp.begin(), tmp.end()) - tmp.begin();
-    }
-    if (entries == 0 || 2 * lines < entries) return 1;
-  }
-  K = std::min(K, kMaxColumnBlocks);
-  const int64_t n_low = std::lower_bound(s.halo_cols.begin(), s.halo_cols.end(), (int32_t)std::min<int64_t>(s.rb, 2147483647)) -
-                        s.halo_cols.begin();
-  const int64_t W = (ext + K - 1) / K;
-  blk.resize((size_t)s.nnz);
-  bool in_order = true;
-  for (int64_t i = 0; i < s.nloc; ++i) {
-    int prev = 0;
-    for (int64_t p = lrp[i]; p < lrp[i + 1]; ++p) {
-      const int64_t lc = lcol[p];
-      int64_t pos;
-      if (lc < s.npad) {
-        pos = n_low + lc;
-      } else {
-        const int64_t h = lc - s.npad;
-        pos = h < n_low ? h : s.nloc + h;
-      }
-      const int k = (int)(pos / W);
-      blk[p] = (uint8_t)k;
-      if (k < prev) in_order = false;
-      prev = k;
-    }
-  }
-  if (request < 0 && !in_order) return 1;  // automatic mode never changes a result
-  return K;
+  const ShardColumns sc{s.nloc, s.npad, s.nhalo, halo_below(s), s.es};
+  return choose_column_blocks(sc, s.nnz, lcol, lrp, request, blk);
 }
 
 template <class T>
@@ -495,8 +451,7 @@ int upload_vec(eigenex_context_s* c, T** dev, const std::vector<T>& host, size_t
 struct GlobalOrder {
   int64_t n_low, npad, nloc;
   explicit GlobalOrder(const CsrShard& s)
-      : n_low(std::lower_bound(s.halo_cols.begin(), s.halo_cols.end(), (int32_t)std::min<int64_t>(s.rb, 2147483647)) - s.halo_cols.begin()),
-        npad(s.npad), nloc(s.nloc) {}
+      : n_low(halo_below(s)), npad(s.npad), nloc(s.nloc) {}
   int64_t operator()(int64_t lc) const {
     if (lc < npad) return n_low + lc;
     const int64_t h = lc - npad;
@@ -806,42 +761,19 @@ int build_shard_host(eigenex_context_s* c, int64_t n_global, int gshard, const i
   }
   s.passes = choose_column_blocks(s, lcol, lrp, column_blocks <= -2 ? -1 : column_blocks, blk);
   if (s.passes > 1) {
-    // stable counting sort of the entries by (pass, row): pass k's entries are contiguous, rows keep stored order
-    const int K = s.passes;
-    const int64_t R = s.nloc + 1;
-    std::vector<int32_t> brp((size_t)K * R, 0), bcol((size_t)s.nnz + 8, 0);
-    bval.assign((size_t)(s.nnz + 8) * es, 0.0);
-    for (int64_t i = 0; i < s.nloc; ++i)
-      for (int64_t p = lrp[i]; p < lrp[i + 1]; ++p) brp[(size_t)blk[p] * R + i + 1]++;
-    int64_t run = 0;
-    for (int k = 0; k < K; ++k) {
-      brp[(size_t)k * R] = (int32_t)run;
-      for (int64_t i = 0; i < s.nloc; ++i) {
-        const int64_t cnt = brp[(size_t)k * R + i + 1];
-        brp[(size_t)k * R + i + 1] = (int32_t)(brp[(size_t)k * R + i] + cnt);
-      }
-      run = brp[(size_t)k * R + s.nloc];
-    }
-    std::vector<int32_t> cur((size_t)K);
-    for (int64_t i = 0; i < s.nloc; ++i) {
-      for (int k = 0; k < K; ++k) cur[k] = brp[(size_t)k * R + i];
-      for (int64_t p = lrp[i]; p < lrp[i + 1]; ++p) {
-        const int64_t q = cur[blk[p]]++;
-        bcol[q] = lcol[p];
-        for (int e = 0; e < es; ++e) bval[(size_t)q * es + e] = vsrc[(size_t)p * es + e];
-      }
-    }
+    std::vector<int32_t> brp, bcol;
+    group_entries_by_pass(s.nloc, s.nnz, s.passes, es, lrp, lcol, vsrc, blk, kCsrTailPad, brp, bcol, bval);
     lrp.swap(brp);
     lcol.swap(bcol);
     vsrc = bval.data();
   }
   const size_t nrp = (size_t)s.passes * (s.nloc + 1);
   HIPCHK(hipMalloc(&s.rowptr, sizeof(int32_t) * nrp));
-  HIPCHK(hipMalloc(&s.col, sizeof(int32_t) * (s.nnz + 8)));
-  HIPCHK(hipMalloc(&s.val, sizeof(double) * (s.nnz + 8) * es));
-  HIPCHK(hipMemsetAsync(s.val, 0, sizeof(double) * (s.nnz + 8) * es, c->stream));
+  HIPCHK(hipMalloc(&s.col, sizeof(int32_t) * (s.nnz + kCsrTailPad)));
+  HIPCHK(hipMalloc(&s.val, sizeof(double) * (s.nnz + kCsrTailPad) * es));
+  HIPCHK(hipMemsetAsync(s.val, 0, sizeof(double) * (s.nnz + kCsrTailPad) * es, c->stream));
   HIPCHK(hipMemcpyAsync(s.rowptr, lrp.data(), sizeof(int32_t) * nrp, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(s.col, lcol.data(), sizeof(int32_t) * (s.nnz + 8), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(s.col, lcol.data(), sizeof(int32_t) * (s.nnz + kCsrTailPad), hipMemcpyHostToDevice, c->stream));
   if (s.nnz) HIPCHK(hipMemcpyAsync(s.val, vsrc, sizeof(double) * s.nnz * es, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;

@@ -310,3 +310,38 @@ def test_split_tiles_layout_builder_under_sanitizers(tmp_path):
     out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert out.returncode == 0, (out.stdout.decode()[-1500:], out.stderr.decode()[-1500:])
     assert b"SPLIT LAYOUT OK" in out.stdout
+
+
+def test_spmv_kernel_host_replay(tmp_path):
+    """Host replay of k_spmv (plain and column-blocked passes) on the very arrays the library uploads and with the very
+    index functions the kernel calls (csrc/csr_passes.hpp, csrc/spmv_index.hpp), under AddressSanitizer + UBSan and with
+    -ffp-contract=off: every load inside its array, every LDS slot written at most once per chunk, every slot a row reads
+    written in the same chunk and holding the right product, rows carried from chunk to chunk and from pass to pass equal to
+    the oracle's row loop bit for bit (tests/cpp/spmv_replay_host.cpp).  Runs the matrices of the GPU test
+    test_spmv_random_structures_bit_exact in their three variants (automatic, plain, forced passes) -- seed 1 is the one
+    that once came back one ulp off in one row on the GPU -- plus corner-case
+    structures generated inside the program."""
+    import shutil
+    import subprocess
+
+    import numpy as np
+    from structures import random_structure
+
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    exe = str(tmp_path / "spmv_replay_host")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-ffp-contract=off",
+                           "-I", os.path.join(ROOT, "cmpt-eigenex_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "cpp", "spmv_replay_host.cpp"), "-o", exe])
+    files = []
+    for seed in (1, 0, 2, 4, 7):
+        n, rowptr, col, val, x, counts, shards, K = random_structure(seed)
+        path = str(tmp_path / f"structure{seed}.bin")
+        with open(path, "wb") as f:
+            np.array([n, col.size, 3, 0, -1, 0, K], np.int64).tofile(f)
+            rowptr.tofile(f), col.tofile(f), val.tofile(f), x.tofile(f)
+        files.append(path)
+    out = subprocess.run([exe] + files, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, (out.stdout.decode()[-3000:], out.stderr.decode()[-1500:])
+    assert b"SPMV REPLAY OK" in out.stdout
+    assert out.stdout.count(b"structure1.bin") == 3  # the recorded case: automatic, plain, six forced passes

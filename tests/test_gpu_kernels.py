@@ -605,26 +605,13 @@ def test_spmv_random_structures_bit_exact(capi, seed):
     """Randomised CSR shapes: tiny and odd row counts, heavy-tailed row lengths (rows longer than several 2048-entry
     LDS chunks next to empty rows), random shard counts and column-block counts -- always bit-identical to the
     oracle's row loop (columns ascending, so column blocking keeps the order)."""
-    rng = np.random.default_rng(1000 + seed)
-    n = int(rng.choice([1, 2, 63, 255, 256, 257, 1000, 4097, 9001]))
-    kind = seed % 3
-    if kind == 0:
-        counts = rng.integers(0, min(n, 9) + 1, n)
-    elif kind == 1:  # heavy tail
-        counts = np.minimum(n, (rng.pareto(0.7, n) * 3).astype(np.int64))
-    else:  # mostly empty, a few very long rows
-        counts = np.where(rng.random(n) < 0.03, rng.integers(0, n + 1, n), 0)
-    counts[rng.integers(0, n)] = min(n, 5000)
-    rowptr = np.zeros(n + 1, np.int64)
-    np.cumsum(counts, out=rowptr[1:])
-    col = np.concatenate([np.sort(rng.choice(n, c, replace=False)) for c in counts] + [np.zeros(0, np.int64)]).astype(np.int32)
-    val = rng.uniform(-1, 1, col.size)
-    x = rng.standard_normal(n)
-    y_ref = cref.csr_spmv(rowptr.astype(np.int32), col, val, x)
-    shards = int(rng.choice([1, 2, 4]))
+    from structures import random_structure
+
+    n, rowptr, col, val, x, counts, shards, K_forced = random_structure(seed)  # the same matrices go through the CPU replay of the kernel
+    y_ref = cref.csr_spmv(rowptr, col, val, x)
     ctx = capi.Context(loopback_shards=shards) if shards > 1 else capi.Context()
-    for K in (None, 0, int(rng.integers(2, 9))):
-        A = capi.Csr.upload(ctx, n, rowptr.astype(np.int32), col, val, column_blocks=K)
+    for K in (None, 0, K_forced):
+        A = capi.Csr.upload(ctx, n, rowptr, col, val, column_blocks=K)
         b = capi.Basis(ctx, A, n, 2)
         b.upload(capi.VEC_W, x)
         dot = b.apply(capi.VEC_W, capi.VEC_V, 0.0, want_dot=True)
@@ -636,7 +623,9 @@ def test_spmv_random_structures_bit_exact(capi, seed):
                 b.upload(capi.VEC_W, x)
                 b.apply(capi.VEC_W, capi.VEC_V, 0.0)
                 again.append(int(np.count_nonzero(b.download(capi.VEC_V) != y_ref)))
-            raise AssertionError(f"SpMV differs from the oracle's row loop: seed {seed} n {n} shards {shards} column_blocks {K} "
+            oracle_again = bool(np.array_equal(cref.csr_spmv(rowptr, col, val, x), y_ref))  # the checker is a suspect too
+            raise AssertionError(f"(the oracle reproduces its own result: {oracle_again}; the kernel's indexing is replayed on the CPU for this "
+                                 f"matrix by test_spmv_kernel_host_replay) "f"SpMV differs from the oracle's row loop: seed {seed} n {n} shards {shards} column_blocks {K} "
                                  f"(passes {A.column_blocks()}), rows {rows[:8]} of lengths {counts[rows[:8]]}, got {y[rows[:4]]!r} want "
                                  f"{y_ref[rows[:4]]!r}; mismatching rows in three repeats: {again}")
         assert abs(dot - x @ y_ref) <= 1e-12 * (np.linalg.norm(x) * np.linalg.norm(y_ref) + 1e-300)
