@@ -1110,53 +1110,88 @@ __global__ __launch_bounds__(kBlock) void k_spmv_z(const int32_t* __restrict__ r
 // a per-tile group table and a hint table for the entry -> group lookup, was built first and ran at less than
 // half the speed of the CSR kernel: 0.34 vs 0.18 ms per application at N = 2e6; this form: 0.147 ms.)
 // ---------------------------------------------------------------------------
+// r3: the input elements of a tile's strips are gathered ONCE per (group, strip column) into LDS by the whole workgroup --
+// the cols array is contiguous over consecutive groups, so the tile's gathers are one flat range -- instead of once per
+// (row, strip column) by every row's lane: rocprofv3 had shown two thirds of the kernel's 8.3e7 L1 accesses per launch to be
+// those per-step index and input loads (profiles/r02_block_sectors.md), with only 55 value requests in flight per CU.  The
+// row walk is then value loads (sixteen in flight) and LDS reads that broadcast within a group.  Same products, same
+// order: bit-identical to the direct form, which remains for tiles whose strips have more columns than the LDS buffer.
+constexpr int kBlockStage = 2048;  // staged input elements per tile (16 KB)
+template <int NB, bool STAGED>
+__device__ __forceinline__ double block_row_walk(const double* __restrict__ v, int64_t nr, int width, const double* xs,
+                                                 const int32_t* __restrict__ cl, const double* __restrict__ x_ext, double scale) {
+  double sum = 0.0;
+  int j = 0;
+  for (; j + NB <= width; j += NB) {
+    double a[NB], xv[NB];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) a[t] = v[(int64_t)(j + t) * nr];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) xv[t] = STAGED ? xs[j + t] : x_ext[cl[j + t]] * scale;
+#pragma unroll
+    for (int t = 0; t < NB; ++t) sum = add_product_nofma(sum, a[t], xv[t]);
+  }
+  if (NB > 8 && j + 8 <= width) {
+    double a[8], xv[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) a[t] = v[(int64_t)(j + t) * nr];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) xv[t] = STAGED ? xs[j + t] : x_ext[cl[j + t]] * scale;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) sum = add_product_nofma(sum, a[t], xv[t]);
+    j += 8;
+  }
+  if (j < width) {  // the last 1..7 columns: their loads in flight together, like a full batch (a serial tail loop cost 3 % at
+                    // strip width 30 -- BASELINE config 5's 10-row sectors -- and 8 % at width 6)
+    const int m = width - j;
+    double a[7], xv[7];
+#pragma unroll
+    for (int t = 0; t < 7; ++t) a[t] = t < m ? v[(int64_t)(j + t) * nr] : 0.0;
+#pragma unroll
+    for (int t = 0; t < 7; ++t) xv[t] = t < m ? (STAGED ? xs[j + t] : x_ext[cl[j + t]] * scale) : 0.0;
+#pragma unroll
+    for (int t = 0; t < 7; ++t)
+      if (t < m) sum = add_product_nofma(sum, a[t], xv[t]);
+  }
+  return sum;
+}
+
 __global__ __launch_bounds__(kBlock) void k_block_spmv(BlockOperatorView op, const double* __restrict__ x_ext,
                                                             const double* __restrict__ scale_ptr, double shift,
                                                             double* __restrict__ y, double* __restrict__ u_out, int64_t n,
                                                             int64_t ntiles, double* __restrict__ partials, int pass,
                                                             const Ctrl* __restrict__ ctrl) {
   __shared__ double lds4[4];
+  __shared__ double xs[kBlockStage];
   if (ctrl->stopped) return;
   const double scale = scale_ptr ? *scale_ptr : 1.0;
   double dot = 0.0;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t r = tile * kBlock + threadIdx.x;
-    if (r >= n) continue;
-    const int g = op.rowgrp[r];
-    const int gr0 = op.grow0[g], nr = op.grow0[g + 1] - gr0;
-    const int64_t ge = op.gent[g];
-    const int width = (int)((op.gent[g + 1] - ge) / nr);
-    const double* v = op.bval + ge + (r - gr0);
-    const int32_t* cl = op.cols + op.gcol[g];
-    double sum = 0.0;
-    int j = 0;
-    for (; j + 8 <= width; j += 8) {
-      double a[8], xv[8];
-#pragma unroll
-      for (int t = 0; t < 8; ++t) a[t] = v[(int64_t)(j + t) * nr];
-#pragma unroll
-      for (int t = 0; t < 8; ++t) xv[t] = x_ext[cl[j + t]] * scale;
-#pragma unroll
-      for (int t = 0; t < 8; ++t) sum = add_product_nofma(sum, a[t], xv[t]);
+    const int64_t r0 = tile * kBlock, r = r0 + threadIdx.x;
+    const int64_t rlast = (r0 + kBlock < n ? r0 + kBlock : n) - 1;
+    const int64_t c_first = op.gcol[op.rowgrp[r0]], c_end = op.gcol[op.rowgrp[rlast] + 1];  // the tile's strip columns: one range of cols
+    const bool staged = c_end - c_first <= kBlockStage;
+    if (staged) {
+      for (int i = threadIdx.x; i < (int)(c_end - c_first); i += kBlock) xs[i] = x_ext[op.cols[c_first + i]] * scale;
+      __syncthreads();
     }
-    if (j < width) {  // the last 1..7 columns: their loads in flight together, like a full batch (a serial tail loop cost 3 % at
-                      // strip width 30 -- BASELINE config 5's 10-row sectors -- and 8 % at width 6)
-      const int m = width - j;
-      double a[7], xv[7];
-#pragma unroll
-      for (int t = 0; t < 7; ++t) a[t] = t < m ? v[(int64_t)(j + t) * nr] : 0.0;
-#pragma unroll
-      for (int t = 0; t < 7; ++t) xv[t] = t < m ? x_ext[cl[j + t]] * scale : 0.0;
-#pragma unroll
-      for (int t = 0; t < 7; ++t)
-        if (t < m) sum = add_product_nofma(sum, a[t], xv[t]);
+    if (r < n) {
+      const int g = op.rowgrp[r];
+      const int gr0 = op.grow0[g], nr = op.grow0[g + 1] - gr0;
+      const int64_t ge = op.gent[g];
+      const int width = (int)((op.gent[g + 1] - ge) / nr);
+      const double* v = op.bval + ge + (r - gr0);
+      const int64_t gc = op.gcol[g];
+      const double sum = staged ? block_row_walk<16, true>(v, nr, width, xs + (gc - c_first), nullptr, nullptr, scale)
+                                : block_row_walk<8, false>(v, nr, width, nullptr, op.cols + gc, x_ext, scale);
+      const double xr = x_ext[r] * scale;
+      double yr = sum;
+      if (shift != 0.0) yr = add_product_nofma(yr, shift, xr);  // lanczos.hpp:390-392
+      y[r] = yr;
+      if (u_out) u_out[r] = xr;
+      dot = (pass & kPassSelfNorm) ? fma(yr, yr, dot) : fma(xr, yr, dot);
     }
-    const double xr = x_ext[r] * scale;
-    double yr = sum;
-    if (shift != 0.0) yr = add_product_nofma(yr, shift, xr);  // lanczos.hpp:390-392
-    y[r] = yr;
-    if (u_out) u_out[r] = xr;
-    dot = (pass & kPassSelfNorm) ? fma(yr, yr, dot) : fma(xr, yr, dot);
+    if (staged) __syncthreads();  // the next tile's staging overwrites xs
   }
   if (partials) {
     dot = block_sum(dot, lds4);
@@ -1166,6 +1201,38 @@ __global__ __launch_bounds__(kBlock) void k_block_spmv(BlockOperatorView op, con
 
 // complex blocks: entries, input and sums are (re, im) pairs; products without contraction and added part by
 // part, exactly like k_spmv_z
+template <int NB, bool STAGED>
+__device__ __forceinline__ double2 block_row_walk_z(const double2* __restrict__ v, int64_t nr, int width, const double2* xs,
+                                                    const int32_t* __restrict__ cl, const double2* __restrict__ x_ext, double scale) {
+  double2 sum = make_double2(0.0, 0.0);
+  auto input = [&](int j) {
+    if (STAGED) return xs[j];
+    double2 x = x_ext[cl[j]];
+    x.x *= scale, x.y *= scale;
+    return x;
+  };
+  int j = 0;
+  for (; j + NB <= width; j += NB) {
+    double2 a[NB], xv[NB];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) a[t] = v[(int64_t)(j + t) * nr];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) xv[t] = input(j + t);
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+      const double2 p = cmul_nofma(a[t], xv[t]);
+      sum.x = sum.x + p.x;
+      sum.y = sum.y + p.y;
+    }
+  }
+  for (; j < width; ++j) {
+    const double2 p = cmul_nofma(v[(int64_t)j * nr], input(j));
+    sum.x = sum.x + p.x;
+    sum.y = sum.y + p.y;
+  }
+  return sum;
+}
+
 __global__ __launch_bounds__(kBlock) void k_block_spmv_z(BlockOperatorView op, const double2* __restrict__ x_ext,
                                                          const double* __restrict__ scale_ptr, double shift_re,
                                                          double shift_im, double2* __restrict__ y,
@@ -1173,62 +1240,53 @@ __global__ __launch_bounds__(kBlock) void k_block_spmv_z(BlockOperatorView op, c
                                                          double* __restrict__ partials, int pstride, int pass,
                                                          const Ctrl* __restrict__ ctrl) {
   __shared__ double lds4[4];
+  __shared__ double2 xs[kBlockStage / 2];  // the tile's input elements, gathered once per (group, strip column) as in k_block_spmv
   if (ctrl->stopped) return;
   const double scale = scale_ptr ? *scale_ptr : 1.0;
   const bool has_shift = shift_re != 0.0 || shift_im != 0.0;
   const double2* bval = reinterpret_cast<const double2*>(op.bval);
   double dr = 0.0, di = 0.0;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t r = tile * kBlock + threadIdx.x;
-    if (r >= n) continue;
-    const int g = op.rowgrp[r];
-    const int gr0 = op.grow0[g], nr = op.grow0[g + 1] - gr0;
-    const int64_t ge = op.gent[g];
-    const int width = (int)((op.gent[g + 1] - ge) / nr);
-    const double2* v = bval + ge + (r - gr0);
-    const int32_t* cl = op.cols + op.gcol[g];
-    double2 sum = make_double2(0.0, 0.0);
-    int j = 0;
-    for (; j + 4 <= width; j += 4) {
-      double2 a[4], xv[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) a[t] = v[(int64_t)(j + t) * nr];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        xv[t] = x_ext[cl[j + t]];
-        xv[t].x *= scale, xv[t].y *= scale;
+    const int64_t r0 = tile * kBlock, r = r0 + threadIdx.x;
+    const int64_t rlast = (r0 + kBlock < n ? r0 + kBlock : n) - 1;
+    const int64_t c_first = op.gcol[op.rowgrp[r0]], c_end = op.gcol[op.rowgrp[rlast] + 1];
+    const bool staged = c_end - c_first <= kBlockStage / 2;
+    if (staged) {
+      for (int i = threadIdx.x; i < (int)(c_end - c_first); i += kBlock) {
+        double2 x = x_ext[op.cols[c_first + i]];
+        x.x *= scale, x.y *= scale;
+        xs[i] = x;
       }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const double2 p = cmul_nofma(a[t], xv[t]);
-        sum.x = sum.x + p.x;
-        sum.y = sum.y + p.y;
+      __syncthreads();
+    }
+    if (r < n) {
+      const int g = op.rowgrp[r];
+      const int gr0 = op.grow0[g], nr = op.grow0[g + 1] - gr0;
+      const int64_t ge = op.gent[g];
+      const int width = (int)((op.gent[g + 1] - ge) / nr);
+      const double2* v = bval + ge + (r - gr0);
+      const int64_t gc = op.gcol[g];
+      const double2 sum = staged ? block_row_walk_z<8, true>(v, nr, width, xs + (gc - c_first), nullptr, nullptr, scale)
+                                 : block_row_walk_z<4, false>(v, nr, width, nullptr, op.cols + gc, x_ext, scale);
+      double2 xr = x_ext[r];
+      xr.x *= scale;
+      xr.y *= scale;
+      double2 yr = sum;
+      if (has_shift) {
+        const double2 t = cmul_nofma(make_double2(shift_re, shift_im), xr);
+        yr.x = yr.x + t.x;
+        yr.y = yr.y + t.y;
+      }
+      y[r] = yr;
+      if (u_out) u_out[r] = xr;
+      if (pass & kPassSelfNorm) {
+        dr = fma(yr.x, yr.x, fma(yr.y, yr.y, dr));  // |y|^2
+      } else {
+        dr = fma(xr.x, yr.x, fma(xr.y, yr.y, dr));  // conj(u) * y
+        di = fma(xr.x, yr.y, fma(-xr.y, yr.x, di));
       }
     }
-    for (; j < width; ++j) {
-      double2 xj = x_ext[cl[j]];
-      xj.x *= scale, xj.y *= scale;
-      const double2 p = cmul_nofma(v[(int64_t)j * nr], xj);
-      sum.x = sum.x + p.x;
-      sum.y = sum.y + p.y;
-    }
-    double2 xr = x_ext[r];
-    xr.x *= scale;
-    xr.y *= scale;
-    double2 yr = sum;
-    if (has_shift) {
-      const double2 t = cmul_nofma(make_double2(shift_re, shift_im), xr);
-      yr.x = yr.x + t.x;
-      yr.y = yr.y + t.y;
-    }
-    y[r] = yr;
-    if (u_out) u_out[r] = xr;
-    if (pass & kPassSelfNorm) {
-      dr = fma(yr.x, yr.x, fma(yr.y, yr.y, dr));  // |y|^2
-    } else {
-      dr = fma(xr.x, yr.x, fma(xr.y, yr.y, dr));  // conj(u) * y
-      di = fma(xr.x, yr.y, fma(-xr.y, yr.x, di));
-    }
+    if (staged) __syncthreads();
   }
   if (partials) {
     dr = block_sum(dr, lds4);

@@ -429,6 +429,14 @@ int finish_send(eigenex_context_s* c, CsrShard& s, const std::vector<int32_t>& i
 // Host-side shard construction from user CSR arrays (global columns).
 // Column blocking (include/eigenex_hip.h, eigenex_csr_upload_ex): csr_passes.hpp -- choose_column_blocks (pass of every stored
 // entry) and group_entries_by_pass (the arrays k_spmv walks), shared with the host replay tests/cpp/spmv_replay_host.cpp.
+// number of partial dots an operator launch leaves (the `nblocks` of the second-stage sums): the grid of k_split_combine, of the
+// sorted tiles, or the persistent grid of k_spmv / k_block_spmv
+int operator_partials(const CsrShard* m, int64_t nloc, int blocks_per_cu) {
+  if (m && m->split) return split_combine_grid(nloc);
+  if (m && m->sorted) return sorted_grid(nloc, m->tile_rows);
+  return grid_for_tiles((nloc + kSpmvRows - 1) / kSpmvRows, blocks_per_cu);
+}
+
 int64_t halo_below(const CsrShard& s) {
   return std::lower_bound(s.halo_cols.begin(), s.halo_cols.end(), (int32_t)std::min<int64_t>(s.rb, 2147483647)) - s.halo_cols.begin();
 }
@@ -2486,9 +2494,10 @@ int eigenex_basis_create_ex(eigenex_context_t c, eigenex_csr_t csr, int64_t n_gl
       HIPCHK(hipMalloc(&s.w, sizeof(double) * (size_t)(s.ldv + s.nhalo + 8) * s.es));
       HIPCHK(hipMemsetAsync(s.w, 0, sizeof(double) * (size_t)(s.ldv + s.nhalo + 8) * s.es, c->stream));
       s.g_vec = grid_for_tiles((s.nd + kTileRows - 1) / kTileRows, kDefaultVecBlocksPerCu);
-      s.g_spmv = (s.csr && s.csr->split) ? split_combine_grid(s.nloc) : (s.csr && s.csr->sorted) ? sorted_grid(s.nloc, s.csr->tile_rows) : grid_for_tiles((s.nloc + kSpmvRows - 1) / kSpmvRows,
-                                                         // long rows: 8 workgroups per CU measured 7-8 % ahead of 4 (scripts/probe_spmv_flags.py); the stencils: equal
-                                                         (s.csr && s.csr->nnz >= 16 * s.csr->nloc) ? 2 * kDefaultSpmvBlocksPerCu : kDefaultSpmvBlocksPerCu);  // (dense blocks the same: the CSR and the block form of one matrix then sum their alpha partials alike)
+      // long rows: 8 workgroups per CU measured 7-8 % ahead of 4 (scripts/probe_spmv_flags.py); the stencils: equal.  Dense blocks (r3:
+      // k_block_spmv stages the input in 16 KB of LDS, nine workgroups fit a CU): 12 -- more workgroups than fit, so that CUs that
+      // finish early take another -- 234.7 / 216.7 / 238.7 / 217.6 / 217.6 us at 4 / 6 / 8 / 12 / 16 (scripts/block_apply.py 10 --sweep)
+      s.g_spmv = operator_partials(s.csr, s.nloc, (s.csr && s.csr->blocked) ? 12 : (s.csr && s.csr->nnz >= 16 * s.csr->nloc) ? 2 * kDefaultSpmvBlocksPerCu : kDefaultSpmvBlocksPerCu);
       // room for eigenex_basis_tune up to kMaxBlocksPerCu workgroups per CU
       s.pstride = std::max(grid_for_tiles((s.nd + kTileRows - 1) / kTileRows, kMaxBlocksPerCu),
                            grid_for_tiles((s.nloc + kSpmvRows - 1) / kSpmvRows, kMaxBlocksPerCu));
@@ -2584,7 +2593,7 @@ int eigenex_basis_tune(eigenex_basis_t b, int vec_blocks_per_cu, int spmv_blocks
     return fail(EIGENEX_ERR_ARG, "eigenex_basis_tune: blocks per CU must be in [1, 16]");
   for (auto& s : b->sh) {
     s.g_vec = grid_for_tiles((s.nd + kTileRows - 1) / kTileRows, vec_blocks_per_cu);
-    s.g_spmv = (s.csr && s.csr->split) ? split_combine_grid(s.nloc) : (s.csr && s.csr->sorted) ? sorted_grid(s.nloc, s.csr->tile_rows) : grid_for_tiles((s.nloc + kSpmvRows - 1) / kSpmvRows, spmv_blocks_per_cu);
+    s.g_spmv = operator_partials(s.csr, s.nloc, spmv_blocks_per_cu);
     s.spmv_flags = flags & 3;  // bit 0: XCD-contiguous tiles, bit 1: non-temporal val/col loads
   }
   return 0;

@@ -11,7 +11,7 @@ sys.path.insert(0, ".")
 import numpy as np
 from cmpt_eigenex_amd import capi, solver
 
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
+args = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and sys.argv[i - 1] != "--json"]
 N = int(args[0]) if len(args) > 0 else 50_000_000
 b = int(args[1]) if len(args) > 1 else 10
 nev = int(args[2]) if len(args) > 2 else 4

@@ -369,6 +369,7 @@ def test_config5_block_hamiltonian_5e7_thick_restart(capi):
     except capi.EigenexError as e:  # pragma: no cover
         pytest.skip(f"not enough device memory for the CSR form: {e}")
     b2 = capi.Basis(ctx, C, N, 13)
+    b2.tune(2, 12, 0)  # the block operator's persistent grid (12 workgroups per CU): alpha's partial sums are then grouped alike
     b2.upload(capi.VEC_W, x)
     b2.apply(capi.VEC_W, capi.VEC_V)
     np.testing.assert_array_equal(b2.download(capi.VEC_V), y_blocks)
