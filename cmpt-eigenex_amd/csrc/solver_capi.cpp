@@ -383,6 +383,40 @@ int eigenex_solver_random_vector_z(uint32_t seed, int64_t n, double* out) {
     std::memcpy(out, v.data(), sizeof(double) * 2 * (size_t)n);
   });
 }
+// ---- SURVEY 8d's synthetic inputs, from the host STL's engines (the engines are specified by the standard; of the
+// distributions only std::normal_distribution is used, as the reference's own samples use it) ------------------------
+// Dense512 (BASELINE config 1): n draws of std::normal_distribution<double>(0, 1) from std::mt19937(seed), in order
+int eigenex_solver_stl_normal(uint32_t seed, int64_t n, double* out) {
+  return guard([&] {
+    std::mt19937 g(seed);
+    std::normal_distribution<double> d(0.0, 1.0);
+    for (int64_t i = 0; i < n; ++i) out[i] = d(g);
+  });
+}
+// RandomCSR (BASELINE config 3): std::mt19937_64(seed) drawn row by row -- first the row's `per` distinct columns
+// (engine() % n, a repeated column is drawn again), stored ascending; then its `per` values in that order, each
+// 2 * ((engine() >> 11) * 2^-53) - 1, i.e. U(-1, 1) from the top 53 bits.  Raw engine output only: the same numbers on any STL.
+int eigenex_solver_random_csr(int64_t n, int per, uint64_t seed, int32_t* rowptr, int32_t* col, double* val) {
+  return guard([&] {
+    if (n <= 0 || per <= 0 || per > n || n > 2147483647 || n * (int64_t)per > 2147483647) throw LanczosException("random_csr: bad size");
+    std::mt19937_64 g(seed);
+    std::vector<int32_t> c((size_t)per);
+    for (int64_t r = 0; r < n; ++r) {
+      rowptr[r] = (int32_t)(r * per);
+      int have = 0;
+      while (have < per) {
+        const int32_t x = (int32_t)(g() % (uint64_t)n);
+        bool seen = false;
+        for (int i = 0; i < have; ++i) seen |= c[(size_t)i] == x;
+        if (!seen) c[(size_t)have++] = x;
+      }
+      std::sort(c.begin(), c.end());
+      std::copy(c.begin(), c.end(), col + r * per);
+      for (int i = 0; i < per; ++i) val[r * per + i] = 2.0 * ((double)(g() >> 11) * 0x1p-53) - 1.0;
+    }
+    rowptr[n] = (int32_t)(n * per);
+  });
+}
 // small dense solvers (small_eigen.hpp); vectors may be NULL
 int eigenex_solver_tridiagonal_eigen(int n, const double* diag, const double* sub, double* values, double* vectors) {
   return guard([&] {

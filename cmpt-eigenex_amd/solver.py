@@ -36,6 +36,8 @@ def lib():
         L.eigenex_solver_default_start_vector.argtypes = [C.c_int64, _dp]
         L.eigenex_solver_random_vector.argtypes = [C.c_uint32, C.c_int64, _dp]
         L.eigenex_solver_random_vector_z.argtypes = [C.c_uint32, C.c_int64, _dp]
+        L.eigenex_solver_stl_normal.argtypes = [C.c_uint32, C.c_int64, _dp]
+        L.eigenex_solver_random_csr.argtypes = [C.c_int64, C.c_int, C.c_uint64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _dp]
         L.eigenex_solver_tridiagonal_eigen.argtypes = [C.c_int, _dp, _dp, _dp, _dp]
         L.eigenex_solver_hessenberg_eigen.argtypes = [C.c_int, _dp, _dp, _dp]
         L.eigenex_solver_symmetric_eigen.argtypes = [C.c_int, _dp, _dp, _dp]
@@ -117,6 +119,21 @@ def random_vector(seed: int, n: int, dtype=np.float64) -> np.ndarray:
     out = np.empty(n)
     _chk(lib().eigenex_solver_random_vector(seed, n, _d(out)))
     return out
+
+
+def stl_normal(seed: int, n: int) -> np.ndarray:
+    """n draws of std::normal_distribution<double>(0, 1) from std::mt19937(seed), in order (the host's <random>)"""
+    out = np.empty(n)
+    _chk(lib().eigenex_solver_stl_normal(seed, n, _d(out)))
+    return out
+
+
+def random_csr(n: int, per: int, seed: int):
+    """SURVEY 8d RandomCSR from std::mt19937_64(seed), row by row (columns, then values): rowptr, col (int32), val"""
+    rowptr, col, val = np.empty(n + 1, np.int32), np.empty(n * per, np.int32), np.empty(n * per)
+    ip = C.POINTER(C.c_int32)
+    _chk(lib().eigenex_solver_random_csr(n, per, seed, rowptr.ctypes.data_as(ip), col.ctypes.data_as(ip), _d(val)))
+    return rowptr, col, val
 
 
 def tridiagonal_eigen(diag, sub, vectors=True):

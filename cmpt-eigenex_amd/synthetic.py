@@ -1,7 +1,9 @@
 """Synthetic operators of BASELINE.md / SURVEY 8d, built on the host with numpy (inputs for bench scripts and tests; the
 7-point Laplacian of the headline workload is generated on the device instead: capi.Csr.laplacian3d).
 
-  random_csr32        BASELINE config 3: N rows, exactly 32 distinct uniformly random columns per row (sorted), U(-1,1)
+  random_csr32        BASELINE config 3: N rows, exactly 32 distinct uniformly random columns per row (sorted), U(-1,1),
+                      from std::mt19937_64(12345) row by row (columns, then values) as SURVEY 8d states it
+  dense512            BASELINE config 1: R_ij ~ N(0,1) from std::mt19937(42) in row-major order, A = (R + R^T)/2
   BlockHamiltonian    BASELINE config 5: block-sparse symmetric "Hamiltonian" in the reference's BlockTensor<double,2>
                       layout (block_tensor.hpp:1193-1206): uniform sectors of size b, stored blocks (q,q), (q,q+-1)
 """
@@ -11,15 +13,26 @@ import numpy as np
 
 
 def random_csr32(N: int, seed: int = 12345, per: int = 32):
-    """rowptr (int32), col (int32, sorted within a row), val (float64)"""
-    rng = np.random.default_rng(seed)
-    col = np.sort(rng.integers(0, N, (N, per), dtype=np.int64), axis=1)
-    bad = np.flatnonzero((np.diff(col, axis=1) == 0).any(axis=1))
-    for r in bad:  # exactly `per` distinct columns per row
-        col[r] = np.sort(rng.choice(N, per, replace=False))
-    val = rng.uniform(-1.0, 1.0, N * per)
-    rowptr = (np.arange(N + 1, dtype=np.int64) * per).astype(np.int32)
-    return rowptr, col.astype(np.int32).ravel(), val
+    """rowptr (int32), col (int32, sorted within a row), val (float64).
+
+    SURVEY 8d: "exactly 32 distinct uniformly random columns per row (sorted), values U(-1,1), std::mt19937_64(12345) drawn
+    row by row (columns first, then values)".  Made precise here with raw engine output only (identical on every STL): a
+    column is engine() % N, drawn again if the row already has it; the row's columns are stored ascending; then one value
+    per stored entry, 2 * ((engine() >> 11) * 2^-53) - 1.  The loop runs in C++ on the host's std::mt19937_64
+    (csrc/solver_capi.cpp: eigenex_solver_random_csr); tests/test_cabi_and_host_logic.py holds it against a pure-Python
+    mt19937_64 on a small case."""
+    from . import solver
+
+    return solver.random_csr(N, per, seed)
+
+
+def dense512(n: int = 512, seed: int = 42):
+    """BASELINE config 1 (SURVEY 8d Dense512): R filled in row-major order with std::normal_distribution<double>(0,1) draws
+    of std::mt19937(seed) -- the host's <random>, as in the reference's own samples -- and A = (R + R^T)/2."""
+    from . import solver
+
+    R = solver.stl_normal(seed, n * n).reshape(n, n)
+    return (R + R.T) / 2
 
 
 class BlockHamiltonian:

@@ -18,7 +18,7 @@ sizes, qr, qc, values, offsets = H.blocks()
 A = capi.Csr.upload_blocks_raw(ctx, sizes, sizes, qr, qc, values, offsets)
 bs = capi.Basis(ctx, A, H.N, 2)
 bs.upload(capi.VEC_W, np.random.default_rng(0).standard_normal(H.N))
-for bpc in ([2, 4, 6, 8, 12, 16] if "--sweep" in sys.argv else [4]):
+for bpc in ([2, 4, 6, 8, 12, 16] if "--sweep" in sys.argv else [12]):
     bs.tune(2, bpc, 0)
     for _ in range(3):
         bs.apply(capi.VEC_W, capi.VEC_V)

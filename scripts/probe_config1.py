@@ -1,10 +1,9 @@
 import sys, time
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np
-from cmpt_eigenex_amd import capi, solver
+from cmpt_eigenex_amd import capi, solver, synthetic
 n = 512
-rng = np.random.default_rng(42)
-R = rng.standard_normal((n, n)); A = (R + R.T) / 2
+A = synthetic.dense512(n)  # SURVEY 8d Dense512: std::mt19937(42) N(0,1), row-major, (R + R^T)/2
 init = solver.default_start_vector(n)
 ctx = capi.Context()
 D = capi.Csr.upload_blocks(ctx, [n], [n], {(0, 0): A})

@@ -17,19 +17,9 @@ out_json = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else N
 per = 32
 
 
-def random_csr32(N, seed):
-    """exactly `per` distinct uniformly random columns per row (sorted), values U(-1, 1) (RandomCSR)"""
-    rng = np.random.default_rng(seed)
-    col = np.sort(rng.integers(0, N, (N, per), dtype=np.int64), axis=1)
-    bad = np.flatnonzero((np.diff(col, axis=1) == 0).any(axis=1))
-    for r in bad:
-        col[r] = np.sort(rng.choice(N, per, replace=False))
-    val = rng.uniform(-1.0, 1.0, N * per)
-    rowptr = (np.arange(N + 1, dtype=np.int64) * per).astype(np.int32)
-    return rowptr, col.astype(np.int32).ravel(), val
+from cmpt_eigenex_amd import synthetic
 
-
-rowptr, col, val = random_csr32(N, 12345)
+rowptr, col, val = synthetic.random_csr32(N, 12345)  # SURVEY 8d RandomCSR: std::mt19937_64(12345), row by row
 nnz = int(rowptr[-1])
 ctx = capi.Context()
 t_up = time.perf_counter()

@@ -345,3 +345,61 @@ def test_spmv_kernel_host_replay(tmp_path):
     assert out.returncode == 0, (out.stdout.decode()[-3000:], out.stderr.decode()[-1500:])
     assert b"SPMV REPLAY OK" in out.stdout
     assert out.stdout.count(b"structure1.bin") == 3  # the recorded case: automatic, plain, six forced passes
+
+
+def test_survey_8d_generators():
+    """SURVEY 8d's synthetic inputs.  RandomCSR: std::mt19937_64(12345) row by row, columns (engine() % N, repeats drawn
+    again, stored ascending) then values (top 53 bits -> U(-1, 1)): the C++ loop on the host STL's engine against a
+    pure-Python MT19937-64 (checked itself against the standard's 10000th output of the default seed).  Dense512:
+    std::mt19937(42) + std::normal_distribution from the host's <random> against oracle/stl_random.py's restatement of
+    libstdc++'s polar method, symmetrised."""
+    import numpy as np
+
+    from cmpt_eigenex_amd import solver, synthetic
+    from oracle import stl_random
+
+    def mt64(seed):
+        mt = [0] * 312
+        mt[0] = seed
+        for i in range(1, 312):
+            mt[i] = (6364136223846793005 * (mt[i - 1] ^ (mt[i - 1] >> 62)) + i) & (2 ** 64 - 1)
+        idx = 312
+        while True:
+            if idx >= 312:
+                for i in range(312):
+                    x = (mt[i] & 0xFFFFFFFF80000000) | (mt[(i + 1) % 312] & 0x7FFFFFFF)
+                    xa = x >> 1
+                    if x & 1:
+                        xa ^= 0xB5026F5AA96619E9
+                    mt[i] = mt[(i + 156) % 312] ^ xa
+                idx = 0
+            y = mt[idx]
+            idx += 1
+            y ^= (y >> 29) & 0x5555555555555555
+            y ^= (y << 17) & 0x71D67FFFEDA60000
+            y ^= (y << 37) & 0xFFF7EEE000000000
+            y ^= y >> 43
+            yield y
+
+    g = mt64(5489)
+    for _ in range(9999):
+        next(g)
+    assert next(g) == 9981545732273789042  # [rand.predef]: 10000th invocation of a default-constructed mt19937_64
+    n, per = 300, 32
+    rowptr, col, val = synthetic.random_csr32(n, 12345, per)
+    assert rowptr.dtype == np.int32 and col.dtype == np.int32 and np.array_equal(rowptr, per * np.arange(n + 1))
+    g = mt64(12345)
+    for r in range(n):
+        cols = []
+        while len(cols) < per:
+            x = next(g) % n
+            if x not in cols:
+                cols.append(x)
+        assert sorted(cols) == list(col[r * per:(r + 1) * per]), r
+        assert [2.0 * ((next(g) >> 11) * 2.0 ** -53) - 1.0 for _ in range(per)] == list(val[r * per:(r + 1) * per]), r
+    big = synthetic.random_csr32(20000, 12345)
+    assert (np.diff(big[1].reshape(-1, 32), axis=1) > 0).all() and np.abs(big[2]).max() < 1.0 and abs(big[2].mean()) < 0.01
+    A = synthetic.dense512(64)
+    R = stl_random.libstdcxx_normal_vector(64 * 64, seed=42).reshape(64, 64)  # n draws in index order, not normalised
+    np.testing.assert_allclose(A, (R + R.T) / 2, rtol=0, atol=4e-16)  # log/sqrt of the libm in use may differ in the last place
+    assert np.array_equal(A, A.T) and abs(A.std() - np.sqrt(0.5 + 0.5 / 64)) < 0.05

@@ -68,15 +68,10 @@ def test_config2_laplacian128_m50_against_oracle_and_properties(capi):
 
 
 def _random_csr32(N, seed):
-    rng = np.random.default_rng(seed)
-    per = 32
-    col = np.sort(rng.integers(0, N, (N, per), dtype=np.int64), axis=1)
-    bad = np.flatnonzero((np.diff(col, axis=1) == 0).any(axis=1))
-    for r in bad:  # exactly 32 distinct columns per row
-        col[r] = np.sort(rng.choice(N, per, replace=False))
-    val = rng.uniform(-1.0, 1.0, N * per)
-    rowptr = (np.arange(N + 1, dtype=np.int64) * per).astype(np.int32)
-    return rowptr, col.astype(np.int32).ravel(), val
+    """SURVEY 8d RandomCSR: std::mt19937_64(seed) row by row, columns then values (cmpt-eigenex_amd/synthetic.py)"""
+    from cmpt_eigenex_amd import synthetic
+
+    return synthetic.random_csr32(N, seed)
 
 
 @pytest.fixture(scope="module")
