@@ -507,7 +507,10 @@ def main():
     achieved = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     # HBM bytes per launch from the PMC passes (rocprofv3 cannot run inside this process): the committed summary of the
     # passes over this same command, profiles/hbm_traffic.json (scripts/summarize_rocprof.py), with its provenance
-    traffic = traffic_src = None
+    # Is that summary from the sources this process runs?  traffic_is_current: the fingerprint of csrc/, the headers and
+    # bench.py recorded with the passes equals the one recomputed here (works on a box without .git); traffic_is_head: no
+    # commit after the recorded one changes those files (`git diff --quiet <commit> HEAD -- ...`; None without a repository).
+    traffic = traffic_src = traffic_commit = traffic_is_current = traffic_is_head = None
     tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tfile):
         try:
@@ -516,6 +519,14 @@ def main():
             traffic = t.get(key, {}).get(kernel_names[dom], {}).get("bytes_per_launch")
             if traffic is not None:
                 traffic_src = f"profiles/hbm_traffic.json[{key}] ({t.get(key, {}).get('__source__', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes')})"
+                traffic_commit = t.get(key, {}).get("__commit__")
+                from cmpt_eigenex_amd.build import source_fingerprint
+                traffic_is_current = t.get(key, {}).get("__sources_sha16__") == source_fingerprint()
+                if os.path.isdir(os.path.join(ROOT, ".git")) and traffic_commit:
+                    import subprocess
+                    rc = subprocess.run(["git", "-C", ROOT, "diff", "--quiet", traffic_commit, "HEAD", "--", "cmpt-eigenex_amd/csrc",
+                                         "cmpt-eigenex_amd/include", "include", "bench.py"], capture_output=True).returncode
+                    traffic_is_head = rc == 0 if rc in (0, 1) else None
         except Exception:
             traffic = None
 
@@ -554,6 +565,9 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
+                "traffic_commit": traffic_commit,
+                "traffic_is_current": traffic_is_current,
+                "traffic_is_head": traffic_is_head,
                 "launches": cnt,
                 "avg_launch_ms": ms / cnt if cnt else None,
                 "algorithmic_bytes_per_launch": by / cnt if cnt else None,

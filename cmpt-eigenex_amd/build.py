@@ -43,6 +43,24 @@ def _all_headers():
     return out
 
 
+def source_fingerprint() -> str:
+    """sha256 (16 hex digits) over the sources that decide what the device runs and what bench.py measures: csrc/*, the C
+    header, the solver classes, bench.py.  Recorded by scripts/summarize_rocprof.py next to the PMC traffic it writes and
+    recomputed by bench.py on the box (which has no .git), so that a stale profiles/hbm_traffic.json shows in the bench line."""
+    import hashlib
+
+    files = []
+    for base in (CSRC, os.path.join(ROOT, "include"), os.path.join(PKG, "include")):
+        for d, _, fs in os.walk(base):
+            files += [os.path.join(d, f) for f in fs if f.endswith((".h", ".hpp", ".hip", ".cpp"))]
+    files.append(os.path.join(ROOT, "bench.py"))
+    h = hashlib.sha256()
+    for f in sorted(files):
+        h.update(os.path.relpath(f, ROOT).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build_hip(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     so = os.path.join(LIBDIR, "libeigenex_hip.so")

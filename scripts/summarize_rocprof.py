@@ -94,6 +94,10 @@ def main():
     tfile = os.path.join(out_dir, "hbm_traffic.json")
     allt = json.load(open(tfile)) if os.path.exists(tfile) else {}
     traffic["__source__"] = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, {source}"
+    traffic["__commit__"] = head
+    sys.path.insert(0, ROOT)
+    from cmpt_eigenex_amd.build import source_fingerprint
+    traffic["__sources_sha16__"] = source_fingerprint()  # bench.py recomputes it: roofline.traffic_is_current
     allt[key] = traffic
     json.dump(allt, open(tfile, "w"), indent=1, sort_keys=True)
     print("\n".join(lines))
