@@ -462,9 +462,13 @@ __device__ __forceinline__ void arnoldi_begin_record(const InlineArnoldiBegin& a
 
 // LONG_ROWS: the row phase reads sixteen products at a time (operators with >= 16 entries per row on average; the short-row form
 // is kept as it was: the same loop in the long-row kernel costs the 7-point stencil 1.8 % through its register allocation)
-template <bool LONG_ROWS>
-__global__ __launch_bounds__(kBlock) void k_spmv(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                                 const double* __restrict__ val, const double* __restrict__ x_ext,
+// OFF: type of the row pointers.  int32_t: a shard with < 2^31 stored entries (every BASELINE config but one 768^3 shard).
+// int64_t (r3; the reference's Index is 64-bit, lanczos.hpp:108-116): the offsets of a TILE are taken relative to the tile's
+// first entry rounded down to a multiple of 4 -- `base`, which moves the col / val pointers -- so that everything behind the
+// row-pointer loads is the same 32-bit arithmetic (spmv_index.hpp) for both types; with int32_t the base is the constant 0.
+template <bool LONG_ROWS, class OFF>
+__global__ __launch_bounds__(kBlock) void k_spmv(const OFF* __restrict__ rowptr, const int32_t* __restrict__ col_all,
+                                                 const double* __restrict__ val_all, const double* __restrict__ x_ext,
                                                  const double* __restrict__ scale_ptr, double shift,
                                                  double* __restrict__ y, double* __restrict__ u_out, int64_t n,
                                                  int64_t ntiles, double* __restrict__ partials, int spmv_flags,
@@ -496,24 +500,32 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int32_t* __restrict__ row
   const TileRange tr = spmv_tiles(ntiles, spmv_flags & 1);
   // row pointers of a tile: fetched one tile ahead, so that their latency is not part of the chain
   // rowptr -> val/col -> x that every tile otherwise pays in sequence
-  auto tile_rows = [&](int64_t tile, int& rs, int& re, int& p0, int& p1) {
+  constexpr bool kWide = sizeof(OFF) > 4;
+  auto tile_rows = [&](int64_t tile, int& rs, int& re, int& p0, int& p1, int64_t& base) {
     rs = re = p0 = p1 = 0;
+    base = 0;
     if (tile >= tr.end) return;
     const int64_t r0 = tile * kSpmvRows, r = r0 + tid;
+    const OFF first = rowptr[r0];
+    if (kWide) base = (int64_t)first & ~(int64_t)3;
     if (r < n) {
-      rs = rowptr[r];
-      re = rowptr[r + 1];
+      rs = (int)(rowptr[r] - (OFF)base);
+      re = (int)(rowptr[r + 1] - (OFF)base);
     }
     const int64_t rend = (r0 + kSpmvRows < n) ? r0 + kSpmvRows : n;
-    p0 = rowptr[r0];
-    p1 = rowptr[rend];
+    p0 = (int)(first - (OFF)base);
+    p1 = (int)(rowptr[rend] - (OFF)base);
   };
   int rs, re, p0, p1;
-  tile_rows(tr.first, rs, re, p0, p1);
+  int64_t base;
+  tile_rows(tr.first, rs, re, p0, p1, base);
   for (int64_t tile = tr.first; tile < tr.end; tile += tr.step) {
     const int64_t r = tile * kSpmvRows + tid;
     int nrs, nre, np0, np1;
-    tile_rows(tile + tr.step, nrs, nre, np0, np1);
+    int64_t nbase;
+    tile_rows(tile + tr.step, nrs, nre, np0, np1, nbase);
+    const int32_t* __restrict__ col = col_all + base;
+    const double* __restrict__ val = val_all + base;
     const int pa = spmv_aligned_start(p0);  // int4 / double2 loads
     double sum = ((pass & kPassCarry) && r < n) ? y[r] : 0.0;  // column-blocked: carry the row sum from pass to pass
     for (int cb = pa; cb < p1; cb += kSpmvChunk) {
@@ -595,7 +607,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const int32_t* __restrict__ row
       if (u_out) u_out[r] = xr;
       dot = (pass & kPassSelfNorm) ? fma(yr, yr, dot) : fma(xr, yr, dot);
     }
-    rs = nrs, re = nre, p0 = np0, p1 = np1;
+    rs = nrs, re = nre, p0 = np0, p1 = np1, base = nbase;
   }
   if (partials) {
     dot = block_sum(dot, lds4);
@@ -1594,9 +1606,10 @@ __device__ __forceinline__ int64_t lap_prefix(int64_t i, int64_t n) {
   return 7 * i - (cx0 + cx1 + cy0 + cy1 + cz0 + cz1);
 }
 
+template <class OFF>
 __global__ __launch_bounds__(kBlock) void k_laplacian3d(int64_t n, int64_t rb, int64_t re, int64_t lower_start,
                                                         int64_t n_lower, int64_t halo_base,
-                                                        int32_t* __restrict__ rowptr, int32_t* __restrict__ col,
+                                                        OFF* __restrict__ rowptr, int32_t* __restrict__ col,
                                                         double* __restrict__ val) {
   const int64_t nloc = re - rb;
   const int64_t n2 = n * n;
@@ -1604,7 +1617,7 @@ __global__ __launch_bounds__(kBlock) void k_laplacian3d(int64_t n, int64_t rb, i
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i <= nloc; i += (int64_t)gridDim.x * kBlock) {
     const int64_t r = rb + i;
     int64_t p = lap_prefix(r, n) - pb;
-    rowptr[i] = (int32_t)p;
+    rowptr[i] = (OFF)p;
     if (i == nloc) break;
     const int64_t x = r % n, yy = (r / n) % n, z = r / n2;
     auto emit = [&](int64_t c, double v) {
@@ -1841,18 +1854,29 @@ void launch_reduce(hipStream_t s, const double* partials, int pstride, int nbloc
   hipLaunchKernelGGL(k_reduce, dim3(ncols), dim3(kBlock), 0, s, partials, pstride, nblocks, out, ctrl);
 }
 
-void launch_spmv(hipStream_t s, const int32_t* rowptr, const int32_t* col, const double* val, const double* x_ext,
-                 const double* scale, double shift, double* y, double* u_out, int64_t n, double* partials, int grid,
-                 const Ctrl* ctrl, int spmv_flags, int pass, const InlineFin* fin, const InlineArnoldiBegin* begin) {
+template <class OFF>
+static void launch_spmv_t(hipStream_t s, const OFF* rowptr, const int32_t* col, const double* val, const double* x_ext,
+                          const double* scale, double shift, double* y, double* u_out, int64_t n, double* partials, int grid,
+                          const Ctrl* ctrl, int spmv_flags, int pass, const InlineFin* fin, const InlineArnoldiBegin* begin) {
   const int64_t ntiles = (n + kSpmvRows - 1) / kSpmvRows;
   const InlineFin nofin{nullptr, 0, 0, 0.0, nullptr, nullptr, nullptr};
   const InlineArnoldiBegin nobegin{nullptr, 0.0, 0, 0, nullptr, 0, 0};
   if (spmv_flags & 4)  // bit 2: long rows
-    hipLaunchKernelGGL(k_spmv<true>, dim3(grid), dim3(kBlock), 0, s, rowptr, col, val, x_ext, scale, shift, y, u_out, n,
+    hipLaunchKernelGGL((k_spmv<true, OFF>), dim3(grid), dim3(kBlock), 0, s, rowptr, col, val, x_ext, scale, shift, y, u_out, n,
                        ntiles, partials, spmv_flags, pass, ctrl, fin ? *fin : nofin, begin ? *begin : nobegin);
   else
-    hipLaunchKernelGGL(k_spmv<false>, dim3(grid), dim3(kBlock), 0, s, rowptr, col, val, x_ext, scale, shift, y, u_out, n,
+    hipLaunchKernelGGL((k_spmv<false, OFF>), dim3(grid), dim3(kBlock), 0, s, rowptr, col, val, x_ext, scale, shift, y, u_out, n,
                        ntiles, partials, spmv_flags, pass, ctrl, fin ? *fin : nofin, begin ? *begin : nobegin);
+}
+void launch_spmv(hipStream_t s, const int32_t* rowptr, const int32_t* col, const double* val, const double* x_ext,
+                 const double* scale, double shift, double* y, double* u_out, int64_t n, double* partials, int grid,
+                 const Ctrl* ctrl, int spmv_flags, int pass, const InlineFin* fin, const InlineArnoldiBegin* begin) {
+  launch_spmv_t(s, rowptr, col, val, x_ext, scale, shift, y, u_out, n, partials, grid, ctrl, spmv_flags, pass, fin, begin);
+}
+void launch_spmv64(hipStream_t s, const int64_t* rowptr, const int32_t* col, const double* val, const double* x_ext,
+                   const double* scale, double shift, double* y, double* u_out, int64_t n, double* partials, int grid,
+                   const Ctrl* ctrl, int spmv_flags, int pass, const InlineFin* fin, const InlineArnoldiBegin* begin) {
+  launch_spmv_t(s, rowptr, col, val, x_ext, scale, shift, y, u_out, n, partials, grid, ctrl, spmv_flags, pass, fin, begin);
 }
 
 void launch_spmv_sorted(hipStream_t s, const SortedOperatorView& op, const double* x_ext, const double* scale, double shift, double* y,
@@ -2008,11 +2032,13 @@ void launch_accept_vector(hipStream_t s, Ctrl* ctrl) {
 }
 
 void launch_laplacian3d(hipStream_t s, int64_t n, int64_t rb, int64_t re, int64_t lower_start, int64_t n_lower,
-                        int64_t halo_base, int32_t* rowptr, int32_t* col, double* val) {
+                        int64_t halo_base, int32_t* rowptr, int64_t* rowptr64, int32_t* col, double* val) {
   const int64_t work = re - rb + 1;
   const int grid = grid_for_tiles((work + kBlock - 1) / kBlock, 8);
-  hipLaunchKernelGGL(k_laplacian3d, dim3(grid), dim3(kBlock), 0, s, n, rb, re, lower_start, n_lower, halo_base, rowptr,
-                     col, val);
+  if (rowptr64)
+    hipLaunchKernelGGL(k_laplacian3d<int64_t>, dim3(grid), dim3(kBlock), 0, s, n, rb, re, lower_start, n_lower, halo_base, rowptr64, col, val);
+  else
+    hipLaunchKernelGGL(k_laplacian3d<int32_t>, dim3(grid), dim3(kBlock), 0, s, n, rb, re, lower_start, n_lower, halo_base, rowptr, col, val);
 }
 
 void launch_ritz(hipStream_t s, const double* V, int64_t ldv, int nvec, const double* St_dev, int ne_pack, int nev,

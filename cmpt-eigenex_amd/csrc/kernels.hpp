@@ -105,6 +105,11 @@ void launch_spmv(hipStream_t s, const int32_t* rowptr, const int32_t* col, const
                  const double* scale, double shift, double* y, double* u_out, int64_t n, double* partials, int grid,
                  const Ctrl* ctrl, int spmv_flags = 0, int pass = 0, const InlineFin* fin = nullptr,
                  const InlineArnoldiBegin* begin = nullptr);
+// the same with 64-bit row pointers (plain real CSR in one pass): a shard may hold >= 2^31 stored entries; col stays int32
+void launch_spmv64(hipStream_t s, const int64_t* rowptr, const int32_t* col, const double* val, const double* x_ext,
+                   const double* scale, double shift, double* y, double* u_out, int64_t n, double* partials, int grid,
+                   const Ctrl* ctrl, int spmv_flags = 0, int pass = 0, const InlineFin* fin = nullptr,
+                   const InlineArnoldiBegin* begin = nullptr);
 // Column-sorted row tiles (real fp64; kernels.hip: k_spmv_sorted): tile t = rows [t*T, (t+1)*T), T = tile_rows, slice k =
 // the k-th range of the operator input (global column order).  Segment (t, k) = entries base[t*(K+1)+k] .. base[t*(K+1)+k+1)
 // of cp/val, sorted by column, padded to a multiple of 4 (val 0, a spare slot); slot = place of the entry in row order
@@ -224,8 +229,9 @@ void launch_accept_vector(hipStream_t s, Ctrl* ctrl);
 // counts malformed row pointers (bad[0]) and out-of-range columns (bad[1]) of a device-resident CSR
 void launch_check_csr(hipStream_t s, const int32_t* rowptr, const int32_t* col, int64_t n, int64_t nnz, int64_t ncols, unsigned int* bad);
 // synthetic 7-point Laplacian rows [rb, re) of an n^3 grid; cols remapped to local/halo numbering
+// rowptr64 != nullptr: 64-bit row pointers (a shard with >= 2^31 stored entries), rowptr unused
 void launch_laplacian3d(hipStream_t s, int64_t n, int64_t rb, int64_t re, int64_t lower_start, int64_t n_lower,
-                        int64_t halo_base, int32_t* rowptr, int32_t* col, double* val);
+                        int64_t halo_base, int32_t* rowptr, int64_t* rowptr64, int32_t* col, double* val);
 
 // Ritz vectors / basis compression: X[:, e] = sum_m St[m*ne_pack + e] * V[:, m] for e < nev <= ne_pack; St is the
 // coefficient block packed [nvec][ne_pack], zero-padded.  ne_pack = 8: also partial squared norms of the results

@@ -194,6 +194,8 @@ struct CsrShard {
   int passes = 1;  // column-blocked: entries grouped by pass, rowptr holds `passes` row-pointer arrays of nloc+1
                    // absolute offsets each (see choose_column_blocks)
   int32_t* rowptr = nullptr;
+  int64_t* rowptr64 = nullptr;  // instead of rowptr when the shard holds >= 2^31 - 16384 stored entries (real plain CSR in one pass;
+                                // r3: the device-generated Laplacian, 768^3 on one MI355X); everything else about the shard is unchanged
   int32_t* col = nullptr;
   double* val = nullptr;
   // column-sorted row tiles (kernels.hpp: SortedOperatorView) instead of rowptr/col/val: scattered gathers over an input
@@ -374,6 +376,7 @@ int halo_exchange(eigenex_basis_s* b, bool use_ctrl = true) {
 
 void free_csr_shard(CsrShard& s) {
   if (s.rowptr) (void)hipFree(s.rowptr);
+  if (s.rowptr64) (void)hipFree(s.rowptr64);
   if (s.col) (void)hipFree(s.col);
   if (s.val) (void)hipFree(s.val);
   if (s.send_idx) (void)hipFree(s.send_idx);
@@ -1275,6 +1278,9 @@ void launch_operator(hipStream_t st, const CsrShard* m, int es, const double* x_
     if (es == 2)
       launch_spmv_z(st, rp, m->col, m->val, x_ext, scale, shift, shift_im, y, u_out, m->nloc, last ? partials : nullptr, pstride,
                     grid, ctrl, flags | (m->nnz >= 16 * m->nloc ? 4 : 0), pass);
+    else if (m->rowptr64)
+      launch_spmv64(st, m->rowptr64, m->col, m->val, x_ext, scale, shift, y, u_out, m->nloc, partials, grid, ctrl,
+                    flags | (m->nnz >= 16 * m->nloc ? 4 : 0), pass, nullptr, begin);
     else
       launch_spmv(st, rp, m->col, m->val, x_ext, scale, shift, y, u_out, m->nloc, last ? partials : nullptr, grid, ctrl,
                   flags | (m->nnz >= 16 * m->nloc ? 4 : 0), pass, nullptr, m->passes == 1 ? begin : nullptr);
@@ -1449,8 +1455,12 @@ int lanczos_step_inline(eigenex_basis_s* b, int k, int first, int stride, int co
   {
     InlineFin fn{s.pnorm, s.g_vec, kFinLanczos, b->threshold, s.beta, s.ctrl, s.hbuf + b->slot_nrm()};
     ProfScope ps(c, EIGENEX_K_SPMV, 12.0 * m->nnz + 4.0 * (m->nloc + 1) + 32.0 * s.nd + 16.0 * s.nd);
-    launch_spmv(st, m->rowptr, m->col, m->val, s.w, nullptr, b->shift, s.v, s.V + (int64_t)(k + 1) * s.ldd, m->nloc, s.palpha, s.g_spmv, s.ctrl,
-                s.spmv_flags | (m->nnz >= 16 * m->nloc ? 4 : 0), 0, &fn);
+    if (m->rowptr64)
+      launch_spmv64(st, m->rowptr64, m->col, m->val, s.w, nullptr, b->shift, s.v, s.V + (int64_t)(k + 1) * s.ldd, m->nloc, s.palpha, s.g_spmv, s.ctrl,
+                    s.spmv_flags | (m->nnz >= 16 * m->nloc ? 4 : 0), 0, &fn);
+    else
+      launch_spmv(st, m->rowptr, m->col, m->val, s.w, nullptr, b->shift, s.v, s.V + (int64_t)(k + 1) * s.ldd, m->nloc, s.palpha, s.g_spmv, s.ctrl,
+                  s.spmv_flags | (m->nnz >= 16 * m->nloc ? 4 : 0), 0, &fn);
   }
   if (last_in_batch) {
     ProfScope ps(c, EIGENEX_K_SMALL, 0.0);
@@ -2350,12 +2360,16 @@ int eigenex_csr_laplacian3d(eigenex_context_t c, int64_t n, eigenex_csr_t* out) 
     s.nloc = s.re - s.rb;
     s.npad = pad_rows(s.nloc);
     s.nnz = nnz_before(s.re) - nnz_before(s.rb);
-    if (s.nnz > (int64_t)2147483647 - 16384) return cleanup(fail(EIGENEX_ERR_ARG, "nnz of a shard must be < 2^31 - 16384"));
+    const bool force_wide = std::getenv("EIGENEX_FORCE_WIDE_ROWPTR") != nullptr;  // tests: the 64-bit kernels on small operators (read per call)
+    const bool wide = force_wide || s.nnz > (int64_t)2147483647 - 16384;
     const int64_t lo = lower(s.rb), hi = upper(s.re);
     const int64_t n_lower = s.rb - lo, n_upper = hi - s.re;
     s.nhalo = n_lower + n_upper;
     if (int rc = [&]() -> int {
-          HIPCHK(hipMalloc(&s.rowptr, sizeof(int32_t) * (s.nloc + 1)));
+          if (wide)
+            HIPCHK(hipMalloc(&s.rowptr64, sizeof(int64_t) * (s.nloc + 1)));
+          else
+            HIPCHK(hipMalloc(&s.rowptr, sizeof(int32_t) * (s.nloc + 1)));
           HIPCHK(hipMalloc(&s.col, sizeof(int32_t) * (s.nnz + 8)));
           HIPCHK(hipMalloc(&s.val, sizeof(double) * (s.nnz + 8)));
           HIPCHK(hipMemsetAsync(s.col + s.nnz, 0, sizeof(int32_t) * 8, c->stream));
@@ -2363,7 +2377,7 @@ int eigenex_csr_laplacian3d(eigenex_context_t c, int64_t n, eigenex_csr_t* out) 
           return 0;
         }())
       return cleanup(rc);
-    launch_laplacian3d(c->stream, n, s.rb, s.re, lo, n_lower, s.npad, s.rowptr, s.col, s.val);
+    launch_laplacian3d(c->stream, n, s.rb, s.re, lo, n_lower, s.npad, s.rowptr, s.rowptr64, s.col, s.val);
     // recv segments: [lo, rb) then [re, hi), split by owner
     auto add_range = [&](int64_t a, int64_t bnd, int64_t hoff) {
       int64_t p = a;

@@ -206,21 +206,23 @@ def test_config4_eight_row_shards_match_single_shard(capi):
     assert np.abs(res[0][2] - res[1][2]).max() < 1e-12
 
 
-def test_largest_laplacian_two_shards_768(capi):
-    """Maximum sizes: 768^3 = 4.5e8 rows, 3.2e9 stored entries (more than int32 can count: two row shards of
-    1.6e9 each, the per-shard limit), 3.6 GB per Krylov vector, ~120 GB on the device.  Checks 64-bit offsets in the
+@pytest.mark.parametrize("shards", [2, 1])
+def test_largest_laplacian_two_shards_768(capi, shards):
+    """Maximum sizes: 768^3 = 4.5e8 rows, 3.2e9 stored entries (more than int32 can count), 3.6 GB per Krylov vector,
+    ~120 GB on the device: as two row shards of 1.6e9 entries each (32-bit row pointers per shard), and -- r3 -- as ONE
+    shard with 64-bit row pointers (the reference's Index is 64-bit, lanczos.hpp:108-116; k_spmv<.., int64_t>).  Checks the
     generator, the kernels and the halo plan through size-independent properties: alpha_0 by hand, beta > 0,
     orthonormality of the basis, Ritz values inside the analytic spectrum, the Lanczos relation."""
     n, m = 768, 8
     N = n ** 3
-    ctx = capi.Context(loopback_shards=2)
+    ctx = capi.Context(loopback_shards=2) if shards == 2 else capi.Context()
     try:
         A = capi.Csr.laplacian3d(ctx, n)
         b = capi.Basis(ctx, A, N, m + 1)
     except capi.EigenexError as e:  # pragma: no cover
         pytest.skip(f"not enough device memory for 768^3: {e}")
     info = A.info()
-    assert info["nnz_local"] == 7 * N - 6 * n * n > 2 ** 31 and info["n_halo_local"] == 2 * n * n
+    assert info["nnz_local"] == 7 * N - 6 * n * n > 2 ** 31 and info["n_halo_local"] == (2 * n * n if shards == 2 else 0)
     init = np.random.default_rng(7).standard_normal(N)
     b.upload(capi.VEC_W, init)
     b.lanczos_enqueue(m + 1)

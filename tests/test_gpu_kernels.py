@@ -781,3 +781,40 @@ def test_finalisers_inside_their_consumer_kernels_change_nothing(capi):
     assert (st.nvec, st.nalpha, st.nbeta, st.stopped, st.calls_true, st.iterations) == (2, 2, 2, 1, 2, 1)
     assert beta[-1] <= 1e-12
     ctx.close()
+
+
+def test_wide_row_pointers_change_nothing(capi, monkeypatch):
+    """64-bit row pointers (a shard with >= 2^31 stored entries; the reference's Index is 64-bit, lanczos.hpp:108-116) forced
+    on a small Laplacian: k_spmv<.., int64_t> takes a tile's offsets relative to the tile's first entry and is otherwise the
+    same arithmetic -- operator output bit-identical to the oracle's row loop, Lanczos coefficients bit-identical to the
+    32-bit run, also with the finalisers inside the kernels, several shards, a shift."""
+    n, m = 37, 12
+    N = n ** 3
+    rowptr, col, val = cref.laplacian3d(n)
+    x = np.random.default_rng(5).standard_normal(N)
+    y_ref = cref.csr_spmv(rowptr, col, val, x)
+    out = {}
+    for wide in (False, True):
+        if wide:
+            monkeypatch.setenv("EIGENEX_FORCE_WIDE_ROWPTR", "1")
+        else:
+            monkeypatch.delenv("EIGENEX_FORCE_WIDE_ROWPTR", raising=False)
+        for shards in (1, 3):
+            ctx = capi.Context(loopback_shards=shards) if shards > 1 else capi.Context()
+            A = capi.Csr.laplacian3d(ctx, n)
+            b = capi.Basis(ctx, A, N, m + 1)
+            b.upload(capi.VEC_W, x)
+            b.apply(capi.VEC_W, capi.VEC_V, 0.0)
+            np.testing.assert_array_equal(b.download(capi.VEC_V), y_ref)
+            b.configure(shift=0.25)
+            b.upload(capi.VEC_W, x)
+            b.lanczos_enqueue(m + 1)
+            st, al, be = b.lanczos_state()
+            assert (st.nvec, st.stopped) == (m + 1, 0)
+            out[(wide, shards)] = (al.copy(), be.copy())
+            b.close()
+            A.close()
+            ctx.close()
+    for shards in (1, 3):
+        np.testing.assert_array_equal(out[(True, shards)][0], out[(False, shards)][0])
+        np.testing.assert_array_equal(out[(True, shards)][1], out[(False, shards)][1])
