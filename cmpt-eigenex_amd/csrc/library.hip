@@ -2508,7 +2508,7 @@ int eigenex_basis_create_ex(eigenex_context_t c, eigenex_csr_t csr, int64_t n_gl
       HIPCHK(hipMalloc(&s.w, sizeof(double) * (size_t)(s.ldv + s.nhalo + 8) * s.es));
       HIPCHK(hipMemsetAsync(s.w, 0, sizeof(double) * (size_t)(s.ldv + s.nhalo + 8) * s.es, c->stream));
       s.g_vec = grid_for_tiles((s.nd + kTileRows - 1) / kTileRows, kDefaultVecBlocksPerCu);
-      // long rows: 8 workgroups per CU measured 7-8 % ahead of 4 (scripts/probe_spmv_flags.py); the stencils: equal.  Dense blocks (r3:
+      // long rows: 8 workgroups per CU measured 7-8 % ahead of 4 (tests/probes/probe_spmv_flags.py); the stencils: equal.  Dense blocks (r3:
       // k_block_spmv stages the input in 16 KB of LDS, nine workgroups fit a CU): 12 -- more workgroups than fit, so that CUs that
       // finish early take another -- 234.7 / 216.7 / 238.7 / 217.6 / 217.6 us at 4 / 6 / 8 / 12 / 16 (scripts/block_apply.py 10 --sweep)
       s.g_spmv = operator_partials(s.csr, s.nloc, (s.csr && s.csr->blocked) ? 12 : (s.csr && s.csr->nnz >= 16 * s.csr->nloc) ? 2 * kDefaultSpmvBlocksPerCu : kDefaultSpmvBlocksPerCu);

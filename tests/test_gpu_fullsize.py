@@ -206,6 +206,30 @@ def test_config4_eight_row_shards_match_single_shard(capi):
     assert np.abs(res[0][2] - res[1][2]).max() < 1e-12
 
 
+def test_automatic_layout_choices_for_the_baseline_configs(capi):
+    """What eigenex_csr_upload / eigenex_block_upload choose by themselves for the BASELINE operators (only
+    config 3's choice was pinned): a 7-point stencil handed over as host CSR stays plain CSR at config 2's size and at the size of
+    one of config 4's eight shards (its gathers coalesce: neither column blocking nor sorted or split tiles, whatever the entry
+    count), config 3 takes the split tiles (test_config3_random_csr_1m_arnoldi_m80 asserts it), config 5's 10-row sectors stay
+    dense blocks and 4-row sectors of the same pattern are stored as CSR (entry-weighted mean sector height < 6)."""
+    from cmpt_eigenex_amd import synthetic
+
+    ctx = capi.Context()
+    for n in (128, 256):  # 128^3 = config 2; 256^3 = 1.17e8 stored entries, the size of one shard of config 4 on 8 GPUs
+        rowptr, col, val = cref.laplacian3d(n)
+        A = capi.Csr.upload(ctx, n ** 3, rowptr, col, val)
+        assert (A.layout(), A.column_blocks()) == ("csr", 1), (n, A.layout())
+        A.close()
+        del rowptr, col, val
+    for b, want in ((10, "dense_blocks"), (4, "csr")):
+        H = synthetic.BlockHamiltonian(400_000, b)
+        sizes, qr, qc, values, offsets = H.blocks()
+        A = capi.Csr.upload_blocks_raw(ctx, sizes, sizes, qr, qc, values, offsets)
+        assert A.layout() == want, (b, A.layout())
+        A.close()
+    ctx.close()
+
+
 @pytest.mark.parametrize("shards", [2, 1])
 def test_largest_laplacian_two_shards_768(capi, shards):
     """Maximum sizes: 768^3 = 4.5e8 rows, 3.2e9 stored entries (more than int32 can count), 3.6 GB per Krylov vector,
