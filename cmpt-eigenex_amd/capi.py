@@ -66,6 +66,7 @@ SIGNATURES = {
     "eigenex_context_info": (C.c_int, [_vp] + [C.POINTER(C.c_int)] * 4),
     "eigenex_context_comm_info": (C.c_int, [_vp] + [C.POINTER(C.c_int)] * 3),
     "eigenex_context_trace": (C.c_int, [_vp, C.c_int]),
+    "eigenex_context_set_halo_overlap": (C.c_int, [_vp, C.c_int]),
     "eigenex_context_trace_get": (C.c_int, [_vp, _ip, _ip, C.c_int, C.POINTER(C.c_int)]),
     "eigenex_plan_create": (C.c_int, [C.c_int64, C.c_int, C.c_int, _ip, _ip, C.POINTER(_vp)]),
     "eigenex_plan_destroy": (C.c_int, [_vp]),
@@ -328,6 +329,13 @@ class Context:
 
     def trace(self, on=True):
         _chk(lib().eigenex_context_trace(self.h, int(on)))
+
+    def set_halo_overlap(self, on=True) -> bool:
+        """neighbour exchange beside the interior rows (True) or in front of the operator (False); returns what is in force"""
+        rc = lib().eigenex_context_set_halo_overlap(self.h, int(on))
+        if rc < 0:
+            _chk(rc)
+        return rc == 1
 
     def trace_get(self):
         n = C.c_int()

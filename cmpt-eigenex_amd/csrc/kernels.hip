@@ -472,7 +472,10 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const OFF* __restrict__ rowptr,
                                                  const double* __restrict__ scale_ptr, double shift,
                                                  double* __restrict__ y, double* __restrict__ u_out, int64_t n,
                                                  int64_t ntiles, double* __restrict__ partials, int spmv_flags,
-                                                 int pass, const Ctrl* ctrl, InlineFin fin, InlineArnoldiBegin ab) {  // no __restrict__ on ctrl: fin.ctrl / ab.ctrl alias it
+                                                 int pass, const Ctrl* ctrl, InlineFin fin, InlineArnoldiBegin ab,
+                                                 const int32_t* __restrict__ tile_list) {  // no __restrict__ on ctrl: fin.ctrl / ab.ctrl alias it
+  // tile_list != nullptr: the launch covers the ntiles tiles tile_list[0 .. ntiles) instead of 0 .. ntiles (r3: the interior
+  // rows of a shard run while the halo is still on its way, the tiles that read halo columns afterwards; library.hip)
   __shared__ double prod[kSpmvProdSlots];
   __shared__ double lds4[4];
   if (ctrl->stopped) return;
@@ -501,10 +504,12 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const OFF* __restrict__ rowptr,
   // row pointers of a tile: fetched one tile ahead, so that their latency is not part of the chain
   // rowptr -> val/col -> x that every tile otherwise pays in sequence
   constexpr bool kWide = sizeof(OFF) > 4;
-  auto tile_rows = [&](int64_t tile, int& rs, int& re, int& p0, int& p1, int64_t& base) {
+  auto tile_rows = [&](int64_t slot, int& rs, int& re, int& p0, int& p1, int64_t& base, int64_t& tile) {
     rs = re = p0 = p1 = 0;
     base = 0;
-    if (tile >= tr.end) return;
+    tile = slot;
+    if (slot >= tr.end) return;
+    if (tile_list) tile = tile_list[slot];
     const int64_t r0 = tile * kSpmvRows, r = r0 + tid;
     const OFF first = rowptr[r0];
     if (kWide) base = (int64_t)first & ~(int64_t)3;
@@ -517,13 +522,13 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const OFF* __restrict__ rowptr,
     p1 = (int)(rowptr[rend] - (OFF)base);
   };
   int rs, re, p0, p1;
-  int64_t base;
-  tile_rows(tr.first, rs, re, p0, p1, base);
-  for (int64_t tile = tr.first; tile < tr.end; tile += tr.step) {
+  int64_t base, tile;
+  tile_rows(tr.first, rs, re, p0, p1, base, tile);
+  for (int64_t slot = tr.first; slot < tr.end; slot += tr.step) {
     const int64_t r = tile * kSpmvRows + tid;
     int nrs, nre, np0, np1;
-    int64_t nbase;
-    tile_rows(tile + tr.step, nrs, nre, np0, np1, nbase);
+    int64_t nbase, ntile;
+    tile_rows(slot + tr.step, nrs, nre, np0, np1, nbase, ntile);
     const int32_t* __restrict__ col = col_all + base;
     const double* __restrict__ val = val_all + base;
     const int pa = spmv_aligned_start(p0);  // int4 / double2 loads
@@ -607,7 +612,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const OFF* __restrict__ rowptr,
       if (u_out) u_out[r] = xr;
       dot = (pass & kPassSelfNorm) ? fma(yr, yr, dot) : fma(xr, yr, dot);
     }
-    rs = nrs, re = nre, p0 = np0, p1 = np1, base = nbase;
+    rs = nrs, re = nre, p0 = np0, p1 = np1, base = nbase, tile = ntile;
   }
   if (partials) {
     dot = block_sum(dot, lds4);
@@ -1857,26 +1862,30 @@ void launch_reduce(hipStream_t s, const double* partials, int pstride, int nbloc
 template <class OFF>
 static void launch_spmv_t(hipStream_t s, const OFF* rowptr, const int32_t* col, const double* val, const double* x_ext,
                           const double* scale, double shift, double* y, double* u_out, int64_t n, double* partials, int grid,
-                          const Ctrl* ctrl, int spmv_flags, int pass, const InlineFin* fin, const InlineArnoldiBegin* begin) {
-  const int64_t ntiles = (n + kSpmvRows - 1) / kSpmvRows;
+                          const Ctrl* ctrl, int spmv_flags, int pass, const InlineFin* fin, const InlineArnoldiBegin* begin,
+                          const int32_t* tile_list, int64_t list_len) {
+  const int64_t ntiles = tile_list ? list_len : (n + kSpmvRows - 1) / kSpmvRows;
+  if (ntiles <= 0) return;
   const InlineFin nofin{nullptr, 0, 0, 0.0, nullptr, nullptr, nullptr};
   const InlineArnoldiBegin nobegin{nullptr, 0.0, 0, 0, nullptr, 0, 0};
   if (spmv_flags & 4)  // bit 2: long rows
     hipLaunchKernelGGL((k_spmv<true, OFF>), dim3(grid), dim3(kBlock), 0, s, rowptr, col, val, x_ext, scale, shift, y, u_out, n,
-                       ntiles, partials, spmv_flags, pass, ctrl, fin ? *fin : nofin, begin ? *begin : nobegin);
+                       ntiles, partials, spmv_flags, pass, ctrl, fin ? *fin : nofin, begin ? *begin : nobegin, tile_list);
   else
     hipLaunchKernelGGL((k_spmv<false, OFF>), dim3(grid), dim3(kBlock), 0, s, rowptr, col, val, x_ext, scale, shift, y, u_out, n,
-                       ntiles, partials, spmv_flags, pass, ctrl, fin ? *fin : nofin, begin ? *begin : nobegin);
+                       ntiles, partials, spmv_flags, pass, ctrl, fin ? *fin : nofin, begin ? *begin : nobegin, tile_list);
 }
 void launch_spmv(hipStream_t s, const int32_t* rowptr, const int32_t* col, const double* val, const double* x_ext,
                  const double* scale, double shift, double* y, double* u_out, int64_t n, double* partials, int grid,
-                 const Ctrl* ctrl, int spmv_flags, int pass, const InlineFin* fin, const InlineArnoldiBegin* begin) {
-  launch_spmv_t(s, rowptr, col, val, x_ext, scale, shift, y, u_out, n, partials, grid, ctrl, spmv_flags, pass, fin, begin);
+                 const Ctrl* ctrl, int spmv_flags, int pass, const InlineFin* fin, const InlineArnoldiBegin* begin,
+                 const int32_t* tile_list, int64_t list_len) {
+  launch_spmv_t(s, rowptr, col, val, x_ext, scale, shift, y, u_out, n, partials, grid, ctrl, spmv_flags, pass, fin, begin, tile_list, list_len);
 }
 void launch_spmv64(hipStream_t s, const int64_t* rowptr, const int32_t* col, const double* val, const double* x_ext,
                    const double* scale, double shift, double* y, double* u_out, int64_t n, double* partials, int grid,
-                   const Ctrl* ctrl, int spmv_flags, int pass, const InlineFin* fin, const InlineArnoldiBegin* begin) {
-  launch_spmv_t(s, rowptr, col, val, x_ext, scale, shift, y, u_out, n, partials, grid, ctrl, spmv_flags, pass, fin, begin);
+                   const Ctrl* ctrl, int spmv_flags, int pass, const InlineFin* fin, const InlineArnoldiBegin* begin,
+                   const int32_t* tile_list, int64_t list_len) {
+  launch_spmv_t(s, rowptr, col, val, x_ext, scale, shift, y, u_out, n, partials, grid, ctrl, spmv_flags, pass, fin, begin, tile_list, list_len);
 }
 
 void launch_spmv_sorted(hipStream_t s, const SortedOperatorView& op, const double* x_ext, const double* scale, double shift, double* y,

@@ -104,12 +104,13 @@ enum { kPassCarry = 1, kPassNotLast = 2, kPassSelfNorm = 4 };
 void launch_spmv(hipStream_t s, const int32_t* rowptr, const int32_t* col, const double* val, const double* x_ext,
                  const double* scale, double shift, double* y, double* u_out, int64_t n, double* partials, int grid,
                  const Ctrl* ctrl, int spmv_flags = 0, int pass = 0, const InlineFin* fin = nullptr,
-                 const InlineArnoldiBegin* begin = nullptr);
+                 const InlineArnoldiBegin* begin = nullptr, const int32_t* tile_list = nullptr, int64_t list_len = 0);
+// (tile_list: the launch covers the 256-row tiles tile_list[0 .. list_len) only -- interior / boundary launches of a shard)
 // the same with 64-bit row pointers (plain real CSR in one pass): a shard may hold >= 2^31 stored entries; col stays int32
 void launch_spmv64(hipStream_t s, const int64_t* rowptr, const int32_t* col, const double* val, const double* x_ext,
                    const double* scale, double shift, double* y, double* u_out, int64_t n, double* partials, int grid,
                    const Ctrl* ctrl, int spmv_flags = 0, int pass = 0, const InlineFin* fin = nullptr,
-                   const InlineArnoldiBegin* begin = nullptr);
+                   const InlineArnoldiBegin* begin = nullptr, const int32_t* tile_list = nullptr, int64_t list_len = 0);
 // Column-sorted row tiles (real fp64; kernels.hip: k_spmv_sorted): tile t = rows [t*T, (t+1)*T), T = tile_rows, slice k =
 // the k-th range of the operator input (global column order).  Segment (t, k) = entries base[t*(K+1)+k] .. base[t*(K+1)+k+1)
 // of cp/val, sorted by column, padded to a multiple of 4 (val 0, a spare slot); slot = place of the entry in row order

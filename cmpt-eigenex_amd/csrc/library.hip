@@ -114,6 +114,15 @@ struct eigenex_context_s {
   std::vector<int> local;         // global ids of the shards this context owns
   hipStream_t stream = nullptr;
   ncclComm_t comm = nullptr;
+  // r3 -- halo exchange beside the interior rows (P > 1): the neighbour send/recv of the operator input runs on a second stream
+  // (and, between real ranks, on a communicator of its own: RCCL wants the operations of ONE communicator issued in one order)
+  // while the compute stream applies the operator to the 256-row tiles that read no halo column; the tiles that do wait for
+  // ev_halo_done.  halo_overlap = false puts the exchange back on the compute stream in front of both launches: same launches,
+  // same sums, same bits (tests compare the two).
+  hipStream_t stream_halo = nullptr;
+  ncclComm_t comm_halo = nullptr;
+  hipEvent_t ev_w_ready = nullptr, ev_halo_done = nullptr;
+  bool halo_overlap = false;
   bool profiling = false;
   bool tracing = false;                      // record every collective the step drivers enqueue (tests)
   std::vector<std::pair<int, int>> trace;    // (EIGENEX_COLL_*, doubles per shard)
@@ -198,6 +207,10 @@ struct CsrShard {
                                 // r3: the device-generated Laplacian, 768^3 on one MI355X); everything else about the shard is unchanged
   int32_t* col = nullptr;
   double* val = nullptr;
+  // plain real CSR in one pass between shards (P > 1): the 256-row tiles that read no halo column / at least one, ascending
+  int32_t *tile_int = nullptr, *tile_bnd = nullptr;
+  int64_t n_tile_int = 0, n_tile_bnd = 0;
+  bool tiles_split = false;
   // column-sorted row tiles (kernels.hpp: SortedOperatorView) instead of rowptr/col/val: scattered gathers over an input
   // larger than L2 (see build_sorted_layout)
   bool sorted = false;
@@ -252,6 +265,7 @@ struct BasisShard {
   Ctrl* ctrl_zero = nullptr;  // always-zero control block for the stand-alone primitives
   Ctrl* ctrl_pass2 = nullptr; // obeyed by the kernels of an adaptive second Gram-Schmidt pass
   int g_vec = 1, g_spmv = 1, pstride = 1, spmv_flags = 0;  // XCD-contiguous SpMV tiles measured 7 % slower at 512^3
+  int g_spmv_int = 0;  // operators launched as interior + boundary tiles: grid (= partial dots) of the interior launch, g_spmv - it of the other
 };
 
 }  // namespace
@@ -331,17 +345,29 @@ int allreduce(eigenex_basis_s* b, int off, int n) {
 }
 
 // fill the halo region of every local shard's operator-input vector
-int halo_exchange(eigenex_basis_s* b, bool use_ctrl = true) {
+// on_halo_stream: the exchange is issued on the context's second stream, behind ev_w_ready (the operator input is complete) and
+// followed by ev_halo_done, which the boundary launch of the operator waits for (enq_apply); else on the compute stream
+int halo_exchange(eigenex_basis_s* b, bool use_ctrl = true, bool on_halo_stream = false) {
   eigenex_context_s* c = b->ctx;
   if (c->P == 1 || !b->csr) return 0;
   if (c->tracing) c->trace.push_back({EIGENEX_COLL_HALO, 0});
   ProfScope ps(c, EIGENEX_K_COMM, 0.0);
+  hipStream_t st = on_halo_stream ? c->stream_halo : c->stream;
+  ncclComm_t comm = on_halo_stream && c->comm_halo ? c->comm_halo : c->comm;
+  if (on_halo_stream) HIPCHK(hipStreamWaitEvent(st, c->ev_w_ready, 0));
+  struct Done {  // ev_halo_done behind whatever was issued, on every return path
+    eigenex_context_s* c;
+    bool on;
+    ~Done() {
+      if (on) (void)hipEventRecord(c->ev_halo_done, c->stream_halo);
+    }
+  } done{c, on_halo_stream};
   // pack non-contiguous send segments
   for (auto& bs : b->sh) {
     CsrShard* cs = bs.csr;
     for (auto& sg : cs->send)
       if (sg.contig_start < 0)
-        launch_pack(c->stream, bs.w, cs->send_idx + sg.offset, sg.count, bs.es, cs->sendbuf + sg.offset * bs.es,
+        launch_pack(st, bs.w, cs->send_idx + sg.offset, sg.count, bs.es, cs->sendbuf + sg.offset * bs.es,
                     use_ctrl ? bs.ctrl : bs.ctrl_zero);
   }
   if (c->loopback) {
@@ -355,7 +381,7 @@ int halo_exchange(eigenex_basis_s* b, bool use_ctrl = true) {
         if (!sg || sg->count != rg.count) return fail(EIGENEX_ERR_STATE, "halo plan mismatch");
         const double* sp = sg->contig_start >= 0 ? src.w + sg->contig_start * src.es : src.csr->sendbuf + sg->offset * src.es;
         HIPCHK(hipMemcpyAsync(bs.w + (bs.ldv + rg.offset) * bs.es, sp, sizeof(double) * rg.count * bs.es,
-                              hipMemcpyDeviceToDevice, c->stream));
+                              hipMemcpyDeviceToDevice, st));
       }
     }
     return 0;
@@ -366,10 +392,10 @@ int halo_exchange(eigenex_basis_s* b, bool use_ctrl = true) {
   NCCLCHK(ncclGroupStart());
   for (auto& sg : cs->send) {
     const double* sp = sg.contig_start >= 0 ? bs.w + sg.contig_start * bs.es : cs->sendbuf + sg.offset * bs.es;
-    NCCLCHK(ncclSend(sp, (size_t)sg.count * bs.es, ncclDouble, sg.peer, c->comm, c->stream));
+    NCCLCHK(ncclSend(sp, (size_t)sg.count * bs.es, ncclDouble, sg.peer, comm, st));
   }
   for (auto& rg : cs->recv)
-    NCCLCHK(ncclRecv(bs.w + (bs.ldv + rg.offset) * bs.es, (size_t)rg.count * bs.es, ncclDouble, rg.peer, c->comm, c->stream));
+    NCCLCHK(ncclRecv(bs.w + (bs.ldv + rg.offset) * bs.es, (size_t)rg.count * bs.es, ncclDouble, rg.peer, comm, st));
   NCCLCHK(ncclGroupEnd());
   return 0;
 }
@@ -377,6 +403,8 @@ int halo_exchange(eigenex_basis_s* b, bool use_ctrl = true) {
 void free_csr_shard(CsrShard& s) {
   if (s.rowptr) (void)hipFree(s.rowptr);
   if (s.rowptr64) (void)hipFree(s.rowptr64);
+  if (s.tile_int) (void)hipFree(s.tile_int);
+  if (s.tile_bnd) (void)hipFree(s.tile_bnd);
   if (s.col) (void)hipFree(s.col);
   if (s.val) (void)hipFree(s.val);
   if (s.send_idx) (void)hipFree(s.send_idx);
@@ -434,10 +462,31 @@ int finish_send(eigenex_context_s* c, CsrShard& s, const std::vector<int32_t>& i
 // entry) and group_entries_by_pass (the arrays k_spmv walks), shared with the host replay tests/cpp/spmv_replay_host.cpp.
 // number of partial dots an operator launch leaves (the `nblocks` of the second-stage sums): the grid of k_split_combine, of the
 // sorted tiles, or the persistent grid of k_spmv / k_block_spmv
-int operator_partials(const CsrShard* m, int64_t nloc, int blocks_per_cu) {
+int operator_partials(const CsrShard* m, int64_t nloc, int blocks_per_cu, int* first_grid = nullptr) {
+  if (first_grid) *first_grid = 0;
   if (m && m->split) return split_combine_grid(nloc);
   if (m && m->sorted) return sorted_grid(nloc, m->tile_rows);
+  if (m && m->tiles_split) {  // two launches (interior tiles, boundary tiles): their partial dots side by side
+    const int g1 = m->n_tile_int ? grid_for_tiles(m->n_tile_int, blocks_per_cu) : 0;
+    const int g2 = m->n_tile_bnd ? grid_for_tiles(m->n_tile_bnd, blocks_per_cu) : 0;
+    if (first_grid) *first_grid = g1;
+    return std::max(g1 + g2, 1);
+  }
   return grid_for_tiles((nloc + kSpmvRows - 1) / kSpmvRows, blocks_per_cu);
+}
+
+// interior / boundary tile lists of a plain CSR shard from a per-tile flag (host), uploaded
+int upload_tile_lists(eigenex_context_s* c, CsrShard& s, const std::vector<uint8_t>& is_boundary) {
+  std::vector<int32_t> ti, tb;
+  for (size_t t = 0; t < is_boundary.size(); ++t) (is_boundary[t] ? tb : ti).push_back((int32_t)t);
+  s.n_tile_int = (int64_t)ti.size(), s.n_tile_bnd = (int64_t)tb.size();
+  HIPCHK(hipMalloc(&s.tile_int, sizeof(int32_t) * (ti.size() + 1)));
+  HIPCHK(hipMalloc(&s.tile_bnd, sizeof(int32_t) * (tb.size() + 1)));
+  if (!ti.empty()) HIPCHK(hipMemcpyAsync(s.tile_int, ti.data(), sizeof(int32_t) * ti.size(), hipMemcpyHostToDevice, c->stream));
+  if (!tb.empty()) HIPCHK(hipMemcpyAsync(s.tile_bnd, tb.data(), sizeof(int32_t) * tb.size(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));  // ti / tb are stack-lifetime staging buffers
+  s.tiles_split = true;
+  return 0;
 }
 
 int64_t halo_below(const CsrShard& s) {
@@ -777,6 +826,16 @@ int build_shard_host(eigenex_context_s* c, int64_t n_global, int gshard, const i
     lrp.swap(brp);
     lcol.swap(bcol);
     vsrc = bval.data();
+  }
+  if (s.passes == 1 && es == 1 && c->P > 1 && s.nloc > 0) {  // which tiles read a halo column (local numbering: >= npad)
+    std::vector<uint8_t> bnd((size_t)((s.nloc + kSpmvRows - 1) / kSpmvRows), 0);
+    for (int64_t r = 0; r < s.nloc; ++r)
+      for (int64_t p = lrp[(size_t)r]; p < lrp[(size_t)r + 1]; ++p)
+        if (lcol[(size_t)p] >= s.npad) {
+          bnd[(size_t)(r / kSpmvRows)] = 1;
+          break;
+        }
+    CHK(upload_tile_lists(c, s, bnd));
   }
   const size_t nrp = (size_t)s.passes * (s.nloc + 1);
   HIPCHK(hipMalloc(&s.rowptr, sizeof(int32_t) * nrp));
@@ -1246,9 +1305,28 @@ int enq_orthogonalize(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_t
 }
 
 // one operator application on one shard: a launch per column-block pass, the row sums carried in y
+// grid_int > 0 (operators with interior / boundary tile lists): two launches, grid_int and grid - grid_int workgroups, their partial
+// dots side by side; halo_done: the second launch waits for it (the halo exchange is on its way on the other stream)
 void launch_operator(hipStream_t st, const CsrShard* m, int es, const double* x_ext, const double* scale, double shift,
                      double shift_im, double* y, double* u_out, double* partials, int pstride, int grid, const Ctrl* ctrl,
-                     int flags, int last_pass_flags = 0, const InlineArnoldiBegin* begin = nullptr) {
+                     int flags, int last_pass_flags = 0, const InlineArnoldiBegin* begin = nullptr, int grid_int = 0,
+                     hipEvent_t halo_done = nullptr) {
+  if (m->tiles_split && !m->split && !m->sorted && !m->blocked && m->passes == 1 && es == 1) {
+    const int fl = flags | (m->nnz >= 16 * m->nloc ? 4 : 0);
+    const int g2 = grid - grid_int;
+    auto go = [&](const int32_t* list, int64_t len, int g, double* part) {
+      if (len <= 0 || g <= 0) return;
+      if (m->rowptr64)
+        launch_spmv64(st, m->rowptr64, m->col, m->val, x_ext, scale, shift, y, u_out, m->nloc, part, g, ctrl, fl, last_pass_flags, nullptr, nullptr, list, len);
+      else
+        launch_spmv(st, m->rowptr, m->col, m->val, x_ext, scale, shift, y, u_out, m->nloc, part, g, ctrl, fl, last_pass_flags, nullptr, nullptr, list, len);
+    };
+    go(m->tile_int, m->n_tile_int, grid_int, partials);
+    if (halo_done) (void)hipStreamWaitEvent(st, halo_done, 0);
+    go(m->tile_bnd, m->n_tile_bnd, g2, partials ? partials + grid_int : nullptr);
+    return;
+  }
+  if (halo_done) (void)hipStreamWaitEvent(st, halo_done, 0);  // layouts that are not split: everything behind the exchange
   if (m->split) {
     const SplitOperatorView op{m->sp_wg, reinterpret_cast<const int4*>(m->sp_chunk), m->sp_cp, m->val, m->sp_groups, m->tile_rows,
                                m->s_nlow, m->npad, m->nloc, m->sp_part, m->npad};
@@ -1311,14 +1389,21 @@ int enq_apply(eigenex_basis_s* b, int ucol, bool want_dot, bool self_norm = fals
   const int merge = (want_dot && alpha_mode >= 0 && fin_merged && b->csr && decides_locally(b)) ? alpha_mode : -1;
   if (fin_merged) *fin_merged = merge >= 0;
   if (b->csr) {
-    CHK(halo_exchange(b));
+    // between shards: the neighbour exchange goes to the halo stream behind ev_w_ready (recorded here: everything that wrote the
+    // operator input is in front of it on the compute stream), the interior tiles run meanwhile, the boundary tiles behind
+    // ev_halo_done.  (Recording the event right behind the update kernel would also overlap the exchange with the all-reduce of
+    // the norm; not done: other writers of the operator input -- copies, restarts -- would have to re-record it.)
+    const bool overlap = c->halo_overlap && c->P > 1;
+    if (overlap) HIPCHK(hipEventRecord(c->ev_w_ready, c->stream));
+    CHK(halo_exchange(b, true, overlap));
+    hipEvent_t halo_done = overlap ? c->ev_halo_done : nullptr;
     for (auto& s : b->sh) {
       CsrShard* m = s.csr;
       if (self_norm) {
         {
           ProfScope ps(c, EIGENEX_K_SPMV, (m->blocked ? 8.0 * b->es * m->nnz + 4.0 * m->nstripcols + 4.0 * m->nloc : (4.0 + 8.0 * b->es) * m->nnz + 4.0 * (m->nloc + 1)) + 32.0 * s.nd);
           launch_operator(c->stream, m, b->es, s.w, &s.ctrl->scale, b->shift, b->shift_im, s.v, s.V + (int64_t)ucol * s.ldd,
-                          defer_self_norm ? s.palpha : s.partials, s.pstride, s.g_spmv, s.ctrl, s.spmv_flags, kPassSelfNorm, begin);
+                          defer_self_norm ? s.palpha : s.partials, s.pstride, s.g_spmv, s.ctrl, s.spmv_flags, kPassSelfNorm, begin, s.g_spmv_int, halo_done);
         }
         if (defer_self_norm) continue;
         ProfScope ps(c, EIGENEX_K_SMALL, 0.0);
@@ -1329,7 +1414,7 @@ int enq_apply(eigenex_basis_s* b, int ucol, bool want_dot, bool self_norm = fals
         const double opbytes = m->blocked ? 8.0 * b->es * m->nnz + 4.0 * m->nstripcols + 4.0 * m->nloc : (4.0 + 8.0 * b->es) * m->nnz + 4.0 * (m->nloc + 1);
         ProfScope ps(c, EIGENEX_K_SPMV, opbytes + 32.0 * s.nd + (want_dot ? 16.0 * s.nd : 0.0));
         launch_operator(c->stream, m, b->es, s.w, &s.ctrl->scale, b->shift, b->shift_im, s.v, s.V + (int64_t)ucol * s.ldd,
-                        want_dot ? s.partials : nullptr, s.pstride, s.g_spmv, s.ctrl, s.spmv_flags, 0, begin);
+                        want_dot ? s.partials : nullptr, s.pstride, s.g_spmv, s.ctrl, s.spmv_flags, 0, begin, s.g_spmv_int, halo_done);
       }
       if (want_dot) {
         ProfScope ps(c, EIGENEX_K_SMALL, 0.0);
@@ -1943,6 +2028,9 @@ static int context_common(eigenex_context_s* c, int device) {
   HIPCHK(hipGetDeviceProperties(&prop, device));
   set_num_cu(prop.multiProcessorCount);
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&c->stream_halo, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_w_ready, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_halo_done, hipEventDisableTiming));
   return 0;
 }
 
@@ -1970,7 +2058,12 @@ int eigenex_context_create(int device, int rank, int world_size, const void* rcc
       delete c;
       return fail(EIGENEX_ERR_RCCL, m);
     }
+    // a communicator of its own for the neighbour exchange, so that it may run on the halo stream beside the all-reduces of the
+    // compute stream (one communicator's operations must be issued in one order).  If it cannot be had, the exchange stays where it was.
+    if (ncclCommSplit(c->comm, 0, rank, &c->comm_halo, nullptr) != ncclSuccess) c->comm_halo = nullptr;
+    (void)hipGetLastError();
   }
+  c->halo_overlap = c->comm_halo != nullptr && std::getenv("EIGENEX_NO_HALO_OVERLAP") == nullptr;
   *out = c;
   return 0;
 }
@@ -2027,6 +2120,7 @@ int eigenex_context_create_loopback(int device, int nshards, eigenex_context_t* 
   c->loopback = true;
   c->P = nshards;
   for (int s = 0; s < nshards; ++s) c->local.push_back(s);
+  c->halo_overlap = nshards > 1 && std::getenv("EIGENEX_NO_HALO_OVERLAP") == nullptr;
   *out = c;
   return 0;
 }
@@ -2039,7 +2133,12 @@ int eigenex_context_destroy(eigenex_context_t c) {
     (void)hipEventDestroy(p.first);
     (void)hipEventDestroy(p.second);
   }
+  if (c->stream_halo) (void)hipStreamSynchronize(c->stream_halo);
+  if (c->comm_halo) (void)ncclCommDestroy(c->comm_halo);
   if (c->comm) (void)ncclCommDestroy(c->comm);
+  if (c->ev_w_ready) (void)hipEventDestroy(c->ev_w_ready);
+  if (c->ev_halo_done) (void)hipEventDestroy(c->ev_halo_done);
+  if (c->stream_halo) (void)hipStreamDestroy(c->stream_halo);
   (void)hipStreamDestroy(c->stream);
   (void)hipGetLastError();
   delete c;
@@ -2050,6 +2149,15 @@ int eigenex_context_sync(eigenex_context_t c) {
   if (!c) return fail(EIGENEX_ERR_ARG, "ctx is NULL");
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
+}
+
+int eigenex_context_set_halo_overlap(eigenex_context_t c, int on) {
+  if (!c) return fail(EIGENEX_ERR_ARG, "ctx is NULL");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream_halo));
+  c->halo_overlap = on != 0 && c->P > 1 && (c->loopback || c->comm_halo != nullptr);
+  return c->halo_overlap ? 1 : 0;
 }
 
 int eigenex_context_info(eigenex_context_t c, int* rank, int* world_size, int* nshards_total, int* nshards_local) {
@@ -2378,6 +2486,18 @@ int eigenex_csr_laplacian3d(eigenex_context_t c, int64_t n, eigenex_csr_t* out) 
         }())
       return cleanup(rc);
     launch_laplacian3d(c->stream, n, s.rb, s.re, lo, n_lower, s.npad, s.rowptr, s.rowptr64, s.col, s.val);
+    if (c->P > 1 && s.nloc > 0) {  // rows that read below the shard: r - n^2 < rb (and r >= n^2); above: r + n^2 >= re (and < N)
+      std::vector<uint8_t> bnd((size_t)((s.nloc + kSpmvRows - 1) / kSpmvRows), 0);
+      const int64_t low_end = std::min(s.re, std::max(s.rb, std::min(s.rb + n2, s.re)));            // rows [rb, low_end) may read [lo, rb)
+      const int64_t high_begin = std::max(s.rb, s.re - n2);                                          // rows [high_begin, re) may read [re, hi)
+      if (n_lower > 0)
+        for (int64_t r = s.rb; r < low_end; r += kSpmvRows) bnd[(size_t)((r - s.rb) / kSpmvRows)] = 1;
+      if (n_lower > 0 && low_end > s.rb) bnd[(size_t)((low_end - 1 - s.rb) / kSpmvRows)] = 1;
+      if (n_upper > 0)
+        for (int64_t r = high_begin; r < s.re; r += kSpmvRows) bnd[(size_t)((r - s.rb) / kSpmvRows)] = 1;
+      if (n_upper > 0) bnd[(size_t)((s.re - 1 - s.rb) / kSpmvRows)] = 1;
+      if (int rc = upload_tile_lists(c, s, bnd)) return cleanup(rc);
+    }
     // recv segments: [lo, rb) then [re, hi), split by owner
     auto add_range = [&](int64_t a, int64_t bnd, int64_t hoff) {
       int64_t p = a;
@@ -2511,10 +2631,10 @@ int eigenex_basis_create_ex(eigenex_context_t c, eigenex_csr_t csr, int64_t n_gl
       // long rows: 8 workgroups per CU measured 7-8 % ahead of 4 (tests/probes/probe_spmv_flags.py); the stencils: equal.  Dense blocks (r3:
       // k_block_spmv stages the input in 16 KB of LDS, nine workgroups fit a CU): 12 -- more workgroups than fit, so that CUs that
       // finish early take another -- 234.7 / 216.7 / 238.7 / 217.6 / 217.6 us at 4 / 6 / 8 / 12 / 16 (scripts/block_apply.py 10 --sweep)
-      s.g_spmv = operator_partials(s.csr, s.nloc, (s.csr && s.csr->blocked) ? 12 : (s.csr && s.csr->nnz >= 16 * s.csr->nloc) ? 2 * kDefaultSpmvBlocksPerCu : kDefaultSpmvBlocksPerCu);
+      s.g_spmv = operator_partials(s.csr, s.nloc, (s.csr && s.csr->blocked) ? 12 : (s.csr && s.csr->nnz >= 16 * s.csr->nloc) ? 2 * kDefaultSpmvBlocksPerCu : kDefaultSpmvBlocksPerCu, &s.g_spmv_int);
       // room for eigenex_basis_tune up to kMaxBlocksPerCu workgroups per CU
       s.pstride = std::max(grid_for_tiles((s.nd + kTileRows - 1) / kTileRows, kMaxBlocksPerCu),
-                           grid_for_tiles((s.nloc + kSpmvRows - 1) / kSpmvRows, kMaxBlocksPerCu));
+                           grid_for_tiles((s.nloc + kSpmvRows - 1) / kSpmvRows, kMaxBlocksPerCu) * ((s.csr && s.csr->tiles_split) ? 2 : 1));  // two launches: two sets of partial dots
       const int rows = 4 * std::max(b->maxcols, 8) + 4;  // two dot sets of a complex column set (fused-alpha step)
       HIPCHK(hipMalloc(&s.partials, sizeof(double) * (size_t)s.pstride * rows));
       HIPCHK(hipMalloc(&s.pnorm, sizeof(double) * (size_t)s.pstride * 2));
@@ -2573,7 +2693,7 @@ int eigenex_basis_clone(eigenex_basis_t src, eigenex_basis_t* out) {
   auto body = [&]() -> int {
     for (size_t i = 0; i < b->sh.size(); ++i) {
       BasisShard &d = b->sh[i], &s = src->sh[i];
-      d.g_vec = s.g_vec, d.g_spmv = s.g_spmv, d.spmv_flags = s.spmv_flags;
+      d.g_vec = s.g_vec, d.g_spmv = s.g_spmv, d.g_spmv_int = s.g_spmv_int, d.spmv_flags = s.spmv_flags;
       const size_t vb = sizeof(double) * (size_t)s.ldd;
       auto cp = [&](void* to, const void* from, size_t bytes) { return hipMemcpyAsync(to, from, bytes, hipMemcpyDeviceToDevice, c->stream); };
       HIPCHK(cp(d.V, s.V, vb * src->cap));
@@ -2607,7 +2727,7 @@ int eigenex_basis_tune(eigenex_basis_t b, int vec_blocks_per_cu, int spmv_blocks
     return fail(EIGENEX_ERR_ARG, "eigenex_basis_tune: blocks per CU must be in [1, 16]");
   for (auto& s : b->sh) {
     s.g_vec = grid_for_tiles((s.nd + kTileRows - 1) / kTileRows, vec_blocks_per_cu);
-    s.g_spmv = operator_partials(s.csr, s.nloc, spmv_blocks_per_cu);
+    s.g_spmv = operator_partials(s.csr, s.nloc, spmv_blocks_per_cu, &s.g_spmv_int);
     s.spmv_flags = flags & 3;  // bit 0: XCD-contiguous tiles, bit 1: non-temporal val/col loads
   }
   return 0;
@@ -2798,7 +2918,7 @@ int eigenex_apply(eigenex_basis_t b, int x_ref, int y_ref, double shift, double*
     CsrShard* m = s.csr;
     ProfScope ps(c, EIGENEX_K_SPMV, (4.0 + 8.0 * b->es) * m->nnz + 4.0 * (m->nloc + 1) + 16.0 * s.nd);
     launch_operator(c->stream, m, b->es, s.w, nullptr, shift, 0.0, vec_ptr(s, b->cap, b->nq, y_ref), nullptr,
-                    dot ? s.partials : nullptr, s.pstride, s.g_spmv, s.ctrl_zero, s.spmv_flags);
+                    dot ? s.partials : nullptr, s.pstride, s.g_spmv, s.ctrl_zero, s.spmv_flags, 0, nullptr, s.g_spmv_int);
     if (dot) launch_reduce(c->stream, s.partials, s.pstride, s.g_spmv, b->es, s.hbuf + b->slot_alpha(), s.ctrl_zero);
   }
   if (dot) {

@@ -155,6 +155,13 @@ int eigenex_context_destroy(eigenex_context_t ctx);
 int eigenex_context_selftest(eigenex_context_t ctx, int* ok);
 int eigenex_context_sync(eigenex_context_t ctx);
 int eigenex_context_info(eigenex_context_t ctx, int* rank, int* world_size, int* nshards_total, int* nshards_local);
+/* Between shards the neighbour exchange of the operator input (no counterpart in the reference, which has no
+ * collective code) runs on a second stream -- between real ranks on a communicator of its own, ncclCommSplit -- while the
+ * operator is applied to the 256-row tiles that read no halo column; the tiles that do wait for it.  on = 0 puts the exchange
+ * back in front of the operator on the compute stream: the same launches and the same bits, for comparison.  Returns 1 if the
+ * overlap is on afterwards, 0 if off (also when asked for but unavailable: one shard, or no second communicator), < 0 on
+ * error.  Default: on where available; EIGENEX_NO_HALO_OVERLAP=1 in the environment turns the default off. */
+int eigenex_context_set_halo_overlap(eigenex_context_t ctx, int on);
 /* what the RCCL communicator itself reports (ncclCommCount / ncclCommUserRank / ncclCommCuDevice): *comm_ranks = 0
  * when the context has no communicator (single GPU, loopback) */
 int eigenex_context_comm_info(eigenex_context_t ctx, int* comm_ranks, int* comm_rank, int* comm_device);

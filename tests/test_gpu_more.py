@@ -703,3 +703,68 @@ def test_collective_schedule_description_matches_the_driver(mods):
                     b.close()
         A.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("shards", [2, 3, 5, 8])
+def test_halo_exchange_beside_interior_rows_changes_nothing(mods, shards):
+    """r3: between shards the neighbour exchange runs on a second stream while the operator is applied to
+    the 256-row tiles that read no halo column; the tiles that do wait for its event.  Switched off, the exchange sits in front
+    of the same two launches on the compute stream: every vector and coefficient must come out bit for bit the same -- a
+    boundary tile that started before its halo had landed, or an interior tile that does read a halo column, would show.
+    Stencil (closed-form halo plan and tile lists) and a random matrix with scattered halo columns (lists from the column
+    scan), Lanczos and the adaptive Arnoldi step, and the stand-alone operator application against the oracle's row loop."""
+    capi, _ = mods
+    rng = np.random.default_rng(77 + shards)
+    n = 23
+    N = n ** 3
+    rp_l, col_l, val_l = cref.laplacian3d(n)
+    per = 9
+    Nr = 20_000
+    col_r = np.sort(rng.integers(0, Nr, (Nr, per)), axis=1).astype(np.int32)
+    col_r[:, 0] = np.minimum(col_r[:, 0], np.arange(Nr))  # keep rows distinct enough; duplicates within a row are fine for CSR
+    col_r = np.sort(col_r, axis=1)
+    rp_r = (np.arange(Nr + 1) * per).astype(np.int32)
+    val_r = rng.uniform(-1, 1, Nr * per)
+    results = {}
+    for overlap in (True, False):
+        ctx = capi.Context(loopback_shards=shards)
+        assert ctx.set_halo_overlap(overlap) == overlap
+        for name, make, size in (("stencil", lambda: capi.Csr.laplacian3d(ctx, n), N),
+                                 ("stencil from host CSR", lambda: capi.Csr.upload(ctx, N, rp_l, col_l, val_l, column_blocks=0), N),
+                                 ("random", lambda: capi.Csr.upload(ctx, Nr, rp_r, col_r.ravel(), val_r, column_blocks=0), Nr)):
+            A = make()
+            x = np.random.default_rng(5).standard_normal(size)
+            b = capi.Basis(ctx, A, size, 16)
+            b.upload(capi.VEC_W, x)
+            b.apply(capi.VEC_W, capi.VEC_V, 0.0)
+            y = b.download(capi.VEC_V)
+            ref = cref.csr_spmv(*((rp_l, col_l, val_l) if size == N else (rp_r, col_r.ravel(), val_r)), x)
+            np.testing.assert_array_equal(y, ref)
+            b.configure(shift=0.125)
+            b.upload(capi.VEC_W, x)
+            b.lanczos_enqueue(15)
+            st, al, be = b.lanczos_state()
+            assert st.nvec == 15 and st.stopped == 0
+            cols = [b.download(capi.VEC_COL(k)) for k in (0, 7, 14)]
+            b.close()
+            b = capi.Basis(ctx, A, size, 12)
+            b.configure(ortho_mode=capi.ORTHO_BATCHED_ADAPTIVE)
+            b.upload(capi.VEC_W, x)
+            b.arnoldi_enqueue(12)
+            st2, H = b.arnoldi_state()
+            assert st2.nvec == 12
+            results[(overlap, name)] = (y, al.copy(), be.copy(), cols, H.copy())
+            b.close()
+            A.close()
+        ctx.close()
+    for name in ("stencil", "stencil from host CSR", "random"):
+        on, off = results[(True, name)], results[(False, name)]
+        np.testing.assert_array_equal(on[0], off[0])
+        np.testing.assert_array_equal(on[1], off[1])
+        np.testing.assert_array_equal(on[2], off[2])
+        for u, v in zip(on[3], off[3]):
+            np.testing.assert_array_equal(u, v)
+        np.testing.assert_array_equal(on[4], off[4])
+    # the generator's closed-form tile lists and the column scan of the same matrix: same launches, same bits
+    np.testing.assert_array_equal(results[(True, "stencil")][1], results[(True, "stencil from host CSR")][1])
+    np.testing.assert_array_equal(results[(True, "stencil")][2], results[(True, "stencil from host CSR")][2])
