@@ -256,10 +256,32 @@ template <bool CPLX, bool RED4, bool DUAL>
 __global__ __launch_bounds__(kBlock) void k_dots(const double* __restrict__ src, ThreeTerm tt, const double* __restrict__ src2,
                                                  ColumnSet cs, int64_t n, int64_t ntiles, double* __restrict__ partials,
                                                  double* __restrict__ partials2, int pstride, const Ctrl* ctrl,  // no __restrict__: fin.ctrl aliases it
-                                                 InlineFin fin) {
+                                                 InlineFin fin, InlineDecide dec) {
   extern __shared__ double lds[];  // [DUAL ? 2 : 1][4 waves][ES*ncols]
   __shared__ double lds4[4];
-  if (ctrl->stopped) return;
+  if (dec.pass2) {  // this launch opens the conditional second Gram-Schmidt pass: does it run?  (k_reduce_decide, taken here)
+    const bool dead = ctrl->stopped != 0;
+    double s = 0.0, sb = 0.0;
+    if (!dead) {
+      for (int b = threadIdx.x; b < dec.after_n; b += kBlock) s += dec.after_partials[b];
+      if (dec.before_partials)
+        for (int b = threadIdx.x; b < dec.before_n; b += kBlock) sb += dec.before_partials[b];
+    }
+    s = block_sum(s, lds4);
+    if (dec.before_partials) sb = block_sum(sb, lds4);
+    else if (!dead) sb = *dec.nrm2_before;
+    const bool again = !dead && s < dec.eta2 * sb;  // Daniel-Gragg-Kaufman-Stewart: the first pass cancelled more than half of the vector
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      if (!dead) {
+        if (dec.before_partials) *dec.nrm2_before = sb;
+        *dec.nrm2_first = s;
+      }
+      dec.pass2->stopped = again ? 0 : 1;
+    }
+    if (!again) return;
+  } else if (ctrl->stopped) {
+    return;
+  }
   constexpr int ES = CPLX ? 2 : 1;
   const int ncols = cs.count + cs.nq;
   const int nacc = ES * ncols;
@@ -368,7 +390,8 @@ __device__ __forceinline__ double update_tile(const double* src, double* dst,  /
 template <bool CPLX>
 __global__ __launch_bounds__(kBlock) void k_update(const double* src, double* dst, ThreeTerm tt, ColumnSet cs,
                                                    const double* __restrict__ h, int64_t n, int64_t ntiles,
-                                                   double* __restrict__ partials, const Ctrl* __restrict__ ctrl) {
+                                                   double* __restrict__ partials, const Ctrl* __restrict__ ctrl, InlineReduce red) {
+  extern __shared__ double h_lds[];  // red.ncoef coefficients when the second-stage sums of the dots pass are taken here
   __shared__ double lds4[4];
   if (ctrl->stopped) return;
   const int ncols = cs.count + cs.nq;
@@ -376,12 +399,32 @@ __global__ __launch_bounds__(kBlock) void k_update(const double* src, double* ds
   const double b = (tt.uk && tt.ukm1) ? *tt.b : 0.0;
   const int ntail = tail_columns(tt, cs);
   double nrm = 0.0;
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t base = tile * kTileRows + 2 * threadIdx.x;
-    if ((tile + 1) * kTileRows <= n)
-      nrm += update_tile<true, CPLX>(src, dst, tt, a, b, cs, ncols, ntail, h, base, n);
-    else
-      nrm += update_tile<false, CPLX>(src, dst, tt, a, b, cs, ncols, ntail, h, base, n);
+  if (red.partials) {  // k_reduce's sums, coefficient by coefficient in its order; workgroup 0 leaves them where k_reduce would have
+    for (int c = 0; c < red.ncoef; ++c) {
+      const double* p = red.partials + (int64_t)c * red.pstride;
+      double sc = 0.0;
+      for (int bb = threadIdx.x; bb < red.nblocks; bb += kBlock) sc += p[bb];
+      sc = block_sum(sc, lds4);
+      if (threadIdx.x == 0) h_lds[c] = sc;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0)
+      for (int c = threadIdx.x; c < red.ncoef; c += kBlock) red.out[c] = h_lds[c];
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      const int64_t base = tile * kTileRows + 2 * threadIdx.x;
+      if ((tile + 1) * kTileRows <= n)
+        nrm += update_tile<true, CPLX>(src, dst, tt, a, b, cs, ncols, ntail, h_lds, base, n);
+      else
+        nrm += update_tile<false, CPLX>(src, dst, tt, a, b, cs, ncols, ntail, h_lds, base, n);
+    }
+  } else {
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      const int64_t base = tile * kTileRows + 2 * threadIdx.x;
+      if ((tile + 1) * kTileRows <= n)
+        nrm += update_tile<true, CPLX>(src, dst, tt, a, b, cs, ncols, ntail, h, base, n);
+      else
+        nrm += update_tile<false, CPLX>(src, dst, tt, a, b, cs, ncols, ntail, h, base, n);
+    }
   }
   nrm = block_sum(nrm, lds4);
   if (threadIdx.x == 0) partials[blockIdx.x] = nrm;
@@ -442,21 +485,64 @@ __device__ __forceinline__ TileRange spmv_tiles(int64_t ntiles, int xcd_sliced) 
   return TileRange{b, G, ntiles};
 }
 
-// InlineArnoldiBegin: returns true if the step must not run (the same test in every workgroup); *scale = 1/residue
-__device__ __forceinline__ bool arnoldi_begin_inline(const InlineArnoldiBegin& ab, double* scale) {
-  const int k = ab.ctrl->nvec;
-  const double res = ab.ctrl->residue;
+// InlineArnoldiBegin: returns true if the step must not run (the same test in every workgroup); *scale = 1/residue.
+// With tail_k >= 0 the previous step is finished first (k_arnoldi_tail): every workgroup forms the same residue from the
+// second pass's partial sums (or takes the first pass's norm) and the step index from the argument -- it reads nothing that
+// workgroup 0 changes; *res_out / *k_out are what the record needs.
+__device__ __forceinline__ bool arnoldi_begin_inline(const InlineArnoldiBegin& ab, double* scale, double* lds4, double* res_out, int* k_out) {
+  int k;
+  double res;
+  if (ab.tail_k >= 0) {
+    const bool second = ab.pass2->stopped == 0;
+    double s = 0.0;
+    if (second && threadIdx.x < kBlock)  // k_arnoldi_tail's sum: 256 strided partial sums, then the four-wave tree (also in a 1024-thread workgroup)
+      for (int b = threadIdx.x; b < ab.tail_nblocks; b += kBlock) s += ab.tail_partials[b];
+    s = wave_sum(s);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0 && threadIdx.x < kBlock) lds4[threadIdx.x >> 6] = s;
+    __syncthreads();
+    s = (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
+    const double nrm2 = second ? s : *ab.nrm2_first;
+    res = sqrt(nrm2);  // arnoldi.hpp:348, :385
+    k = ab.tail_k + 1;
+  } else {
+    k = ab.ctrl->nvec;
+    res = ab.ctrl->residue;
+  }
   const bool stop = (int64_t)k == ab.n_global || res <= ab.threshold || k >= ab.cap;  // arnoldiStepIsUtmost  arnoldi.hpp:277-288
   *scale = 1.0 / res;                                                                   // arnoldi.hpp:365
+  *res_out = res;
+  *k_out = k;
   return stop;
 }
-__device__ __forceinline__ void arnoldi_begin_record(const InlineArnoldiBegin& ab, bool stop, double scale) {
+// workgroup 0, all threads (the copy of h into H is spread over them); `stop`, `scale`, `res`, `k` as derived above
+__device__ __forceinline__ void arnoldi_begin_record(const InlineArnoldiBegin& ab, bool stop, double scale, double res, int k) {
+  if (ab.tail_k >= 0) {  // k_arnoldi_tail for the vector with index tail_k = k - 1
+    const bool second = ab.pass2->stopped == 0;
+    const int kk = ab.tail_k;
+    for (int i = threadIdx.x; i < (kk + 1) * ab.es; i += blockDim.x) {
+      double hv = ab.h[i];
+      if (second && i < ab.ncoef) hv += ab.h2[i], ab.h[i] = hv;
+      ab.H[(int64_t)kk * ab.ldh * ab.es + i] = hv;  // arnoldi.hpp:380-383
+    }
+    if (second)
+      for (int i = (kk + 1) * ab.es + threadIdx.x; i < ab.ncoef; i += blockDim.x) ab.h[i] += ab.h2[i];  // coefficients of the orthogonalizing vectors
+    if (threadIdx.x == 0) {
+      *ab.nrm2_final = res * res;
+      for (int e = 0; e < ab.es; ++e) ab.H[((int64_t)kk * ab.ldh + kk + 1) * ab.es + e] = 0.0;  // arnoldi.hpp:384
+      ab.ctrl->residue = res;
+      ab.ctrl->nvec = kk + 1;
+      ab.ctrl->nalpha = kk + 1;
+      ab.ctrl->iterations++;
+      ab.ctrl->calls_true++;
+    }
+  }
+  if (threadIdx.x != 0) return;
   if (stop) {
     ab.ctrl->stopped = 1;
     return;
   }
-  const int k = ab.ctrl->nvec;
-  ab.H[((int64_t)(k - 1) * ab.ldh + k) * ab.es] = ab.ctrl->residue;  // arnoldi.hpp:363 (imaginary part stays 0)
+  ab.H[((int64_t)(k - 1) * ab.ldh + k) * ab.es] = res;  // arnoldi.hpp:363 (imaginary part stays 0)
   ab.ctrl->scale = scale;
 }
 
@@ -481,9 +567,11 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const OFF* __restrict__ rowptr,
   if (ctrl->stopped) return;
   double scale = (scale_ptr && !ab.ctrl) ? *scale_ptr : 1.0;
   if (ab.ctrl) {
-    const bool stop = arnoldi_begin_inline(ab, &scale);
+    double res;
+    int kb;
+    const bool stop = arnoldi_begin_inline(ab, &scale, lds4, &res, &kb);
     __syncthreads();  // everybody has read the control block before workgroup 0 changes it (other workgroups: the values written are the ones they derived)
-    if (blockIdx.x == 0 && threadIdx.x == 0) arnoldi_begin_record(ab, stop, scale);
+    if (blockIdx.x == 0) arnoldi_begin_record(ab, stop, scale, res, kb);
     if (stop) return;
   }
   if (fin.partials) {  // beta_k, the breakdown test and the scale of the operator input (lanczos.hpp:429-439), taken here
@@ -835,12 +923,15 @@ template <int DEPTH>
 __global__ __launch_bounds__(kSplitBlock) void k_spmv_split(SplitOperatorView op, const double* __restrict__ x_ext,
                                                            const double* __restrict__ scale_ptr, const Ctrl* ctrl, InlineArnoldiBegin ab) {
   extern __shared__ double lds_acc[];  // tile_rows partial row sums
+  __shared__ double lds4b[4];
   if (ctrl->stopped) return;
   double scale = (scale_ptr && !ab.ctrl) ? *scale_ptr : 1.0;
   if (ab.ctrl) {  // the second kernel (k_split_combine) reads the control block after workgroup 0 of this one has recorded
-    const bool stop = arnoldi_begin_inline(ab, &scale);
+    double res;
+    int kb;
+    const bool stop = arnoldi_begin_inline(ab, &scale, lds4b, &res, &kb);
     __syncthreads();
-    if (blockIdx.x == 0 && threadIdx.x == 0) arnoldi_begin_record(ab, stop, scale);
+    if (blockIdx.x == 0) arnoldi_begin_record(ab, stop, scale, res, kb);
     if (stop) return;
   }
   const int tid = threadIdx.x, T = op.tile_rows;
@@ -1792,7 +1883,8 @@ int grid_for_tiles(int64_t ntiles, int blocks_per_cu) {
 void set_num_cu(int n) { g_num_cu = n > 0 ? n : 256; }
 
 void launch_dots(hipStream_t s, const double* src, ThreeTerm tt, ColumnSet cs, int64_t n, double* partials,
-                 int pstride, int grid, const Ctrl* ctrl, bool cplx, const double* src2, double* partials2, const InlineFin* fin) {
+                 int pstride, int grid, const Ctrl* ctrl, bool cplx, const double* src2, double* partials2, const InlineFin* fin,
+                 const InlineDecide* dec) {
   const int ncols = cs.count + cs.nq;
   if (ncols <= 0) return;
   const int64_t ntiles = (n + kTileRows - 1) / kTileRows;
@@ -1803,8 +1895,10 @@ void launch_dots(hipStream_t s, const double* src, ThreeTerm tt, ColumnSet cs, i
   }();
   const InlineFin nofin{nullptr, 0, 0, 0.0, nullptr, nullptr, nullptr};
   const InlineFin f = fin ? *fin : nofin;
+  const InlineDecide nodec{nullptr, nullptr, 0, nullptr, 0, 0.0, nullptr, nullptr};
+  const InlineDecide dd = dec ? *dec : nodec;
 #define EIGENEX_LAUNCH_DOTS(C, R, D) \
-  hipLaunchKernelGGL((k_dots<C, R, D>), dim3(grid), dim3(kBlock), shmem, s, src, tt, src2, cs, n, ntiles, partials, partials2, pstride, ctrl, f)
+  hipLaunchKernelGGL((k_dots<C, R, D>), dim3(grid), dim3(kBlock), shmem, s, src, tt, src2, cs, n, ntiles, partials, partials2, pstride, ctrl, f, dd)
   if (src2) {
     if (cplx)
       EIGENEX_LAUNCH_DOTS(true, true, true);
@@ -1825,12 +1919,15 @@ void launch_dots(hipStream_t s, const double* src, ThreeTerm tt, ColumnSet cs, i
 }
 
 void launch_update(hipStream_t s, const double* src, double* dst, ThreeTerm tt, ColumnSet cs, const double* h,
-                   int64_t n, double* partials, int grid, const Ctrl* ctrl, bool cplx) {
+                   int64_t n, double* partials, int grid, const Ctrl* ctrl, bool cplx, const InlineReduce* red) {
   const int64_t ntiles = (n + kTileRows - 1) / kTileRows;
+  const InlineReduce nored{nullptr, 0, 0, 0, nullptr};
+  const InlineReduce r = red ? *red : nored;
+  const size_t shmem = red ? sizeof(double) * (size_t)red->ncoef : 0;
   if (cplx)
-    hipLaunchKernelGGL(k_update<true>, dim3(grid), dim3(kBlock), 0, s, src, dst, tt, cs, h, n, ntiles, partials, ctrl);
+    hipLaunchKernelGGL(k_update<true>, dim3(grid), dim3(kBlock), shmem, s, src, dst, tt, cs, h, n, ntiles, partials, ctrl, r);
   else
-    hipLaunchKernelGGL(k_update<false>, dim3(grid), dim3(kBlock), 0, s, src, dst, tt, cs, h, n, ntiles, partials, ctrl);
+    hipLaunchKernelGGL(k_update<false>, dim3(grid), dim3(kBlock), shmem, s, src, dst, tt, cs, h, n, ntiles, partials, ctrl, r);
 }
 
 void launch_spmv_z(hipStream_t s, const int32_t* rowptr, const int32_t* col, const double* val, const double* x_ext,
@@ -1867,7 +1964,7 @@ static void launch_spmv_t(hipStream_t s, const OFF* rowptr, const int32_t* col, 
   const int64_t ntiles = tile_list ? list_len : (n + kSpmvRows - 1) / kSpmvRows;
   if (ntiles <= 0) return;
   const InlineFin nofin{nullptr, 0, 0, 0.0, nullptr, nullptr, nullptr};
-  const InlineArnoldiBegin nobegin{nullptr, 0.0, 0, 0, nullptr, 0, 0};
+  const InlineArnoldiBegin nobegin{nullptr, 0.0, 0, 0, nullptr, 0, 0, -1, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
   if (spmv_flags & 4)  // bit 2: long rows
     hipLaunchKernelGGL((k_spmv<true, OFF>), dim3(grid), dim3(kBlock), 0, s, rowptr, col, val, x_ext, scale, shift, y, u_out, n,
                        ntiles, partials, spmv_flags, pass, ctrl, fin ? *fin : nofin, begin ? *begin : nobegin, tile_list);
@@ -1926,7 +2023,7 @@ void launch_spmv_split(hipStream_t s, const SplitOperatorView& op, const double*
                        double* u_out, int64_t n, double* partials, const Ctrl* ctrl, int pass, const InlineArnoldiBegin* begin) {
   const auto kernel = k_spmv_split_used;
   (void)prepare_spmv_split();
-  const InlineArnoldiBegin nobegin{nullptr, 0.0, 0, 0, nullptr, 0, 0};
+  const InlineArnoldiBegin nobegin{nullptr, 0.0, 0, 0, nullptr, 0, 0, -1, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
   const int64_t ntiles = (n + op.tile_rows - 1) / op.tile_rows;
   hipLaunchKernelGGL(kernel, dim3((unsigned)(ntiles * op.groups)), dim3(kSplitBlock), sizeof(double) * op.tile_rows, s, op, x_ext,
                      scale, ctrl, begin ? *begin : nobegin);

@@ -68,6 +68,43 @@ struct InlineArnoldiBegin {
   int cap;
   double* H;
   int ldh, es;
+  // r3: the END of the previous step (k_arnoldi_tail: the second pass's norm, h += h2, the choice of the norm, residue,
+  // column k of H, the counters) taken here too, in front of the begin: tail_k >= 0 is the index of the vector the previous
+  // step added (known to the host), so that no workgroup needs a counter that workgroup 0 is changing.  -1: off.
+  int tail_k;
+  const double* tail_partials;  // ||w||^2 partial sums of the second pass's update kernel
+  int tail_nblocks;
+  const Ctrl* pass2;            // stopped == 0: the second pass ran
+  double* h;
+  const double* h2;
+  int ncoef;
+  const double* nrm2_first;
+  double* nrm2_final;
+};
+
+// The decision "second Gram-Schmidt pass or not" (k_reduce_decide) taken by the FIRST kernel of that pass itself: every
+// workgroup of k_dots adds the first pass's norm partials (and the operator's ||v||^2 partials) in k_reduce's order and
+// arrives at the same verdict; workgroup 0 records it (pass2->stopped, the two norms) for the kernels that follow.
+// pass2 == nullptr: off.
+struct InlineDecide {
+  Ctrl* pass2;
+  const double* after_partials;
+  int after_n;
+  const double* before_partials;  // nullptr: *nrm2_before already holds ||v||^2
+  int before_n;
+  double eta2;
+  double* nrm2_first;
+  double* nrm2_before;
+};
+
+// The second-stage sums of a dots pass (k_reduce: h_c = sum_b partials[c*pstride + b]) taken by the update kernel that
+// consumes them: every workgroup forms all ncoef sums in k_reduce's order into LDS (workgroup 0 also leaves them in `out`).
+// Only for the conditional second pass, which normally does not run: there it saves a launch per step, and when it does run
+// the repeated sums (ncoef x nblocks loads per workgroup) are small beside the pass over the basis.  partials == nullptr: off.
+struct InlineReduce {
+  const double* partials;
+  int pstride, nblocks, ncoef;
+  double* out;
 };
 
 int grid_for_tiles(int64_t ntiles, int blocks_per_cu);
@@ -80,12 +117,13 @@ void set_num_cu(int n);
 // fin (real, single source only): alpha_k = sum of the operator kernel's partials, taken inside this kernel (InlineFin)
 void launch_dots(hipStream_t s, const double* src, ThreeTerm tt, ColumnSet cs, int64_t n, double* partials,
                  int pstride, int grid, const Ctrl* ctrl, bool cplx, const double* src2 = nullptr, double* partials2 = nullptr,
-                 const InlineFin* fin = nullptr);
+                 const InlineFin* fin = nullptr, const InlineDecide* dec = nullptr);
 // fused-alpha Lanczos step: h[i] = g[i] - alpha*G[i] from fused = [alpha, -, g (ncoef), G (ncoef)]; alpha joins the series
 void launch_form_h(hipStream_t s, Ctrl* ctrl, const double* fused, int ncoef, double* h, double* alpha, int first);
 // dst = w0 - sum_c h[c]*col_c (sequential in c); partials[block] = partial ||dst||^2
 void launch_update(hipStream_t s, const double* src, double* dst, ThreeTerm tt, ColumnSet cs, const double* h,
-                   int64_t n, double* partials, int grid, const Ctrl* ctrl, bool cplx);
+                   int64_t n, double* partials, int grid, const Ctrl* ctrl, bool cplx, const InlineReduce* red = nullptr);
+constexpr int kInlineReduceMaxCoef = 4096;  // 32 KB of LDS for the coefficients
 // complex operator: n = rows; val/x/y/u_out interleaved (re, im); partials[block] = re, partials[pstride+block] = im of conj(u).y
 void launch_spmv_z(hipStream_t s, const int32_t* rowptr, const int32_t* col, const double* val, const double* x_ext,
                    const double* scale, double shift_re, double shift_im, double* y, double* u_out, int64_t n,

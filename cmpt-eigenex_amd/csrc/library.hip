@@ -288,6 +288,8 @@ struct StepGraph {
 };
 
 struct eigenex_basis_s {
+  bool tail_pending = false;  // Arnoldi, one shard: the end of the last enqueued step (k_arnoldi_tail) is left to the next step's operator kernel
+  int tail_ncoef = 0;         //   number of doubles of that step's coefficient vector
   eigenex_context_s* ctx = nullptr;
   eigenex_csr_s* csr = nullptr;
   int64_t n_global = 0;
@@ -1111,8 +1113,11 @@ int place_work_vector(eigenex_context_s* c, BasisShard& s, int capacity) {
 // 2 = the second-pass control block of the adaptive Gram-Schmidt
 inline const Ctrl* pick_ctrl(const BasisShard& s, int use_ctrl) { return use_ctrl == 2 ? s.ctrl_pass2 : use_ctrl ? s.ctrl : s.ctrl_zero; }
 
+// dec (one shard): this pass is the conditional second one and its first launch takes the decision itself (InlineDecide): it runs
+// under the state's control block, later chunks under the second-pass block that it has set.  skip_reduce: the consumer kernel
+// forms the second-stage sums (InlineReduce).
 int enq_dots(eigenex_basis_s* b, int src_ref, bool three_term, int k, int first, int stride, int count, int qfirst,
-             int nq, int slot, int use_ctrl, int base = 0) {
+             int nq, int slot, int use_ctrl, int base = 0, const InlineDecide* dec = nullptr, bool skip_reduce = false) {
   eigenex_context_s* c = b->ctx;
   const int ncols = count + nq;
   if (ncols <= 0) return 0;
@@ -1131,10 +1136,13 @@ int enq_dots(eigenex_basis_s* b, int src_ref, bool three_term, int k, int first,
       const int q0 = std::max(c0 - count, 0), q1 = std::max(c0 + nc - count, 0);
       ProfScope ps(c, EIGENEX_K_DOTS, use_ctrl == 2 ? 0.0 : 8.0 * s.nd * nc + 8.0 * s.nd);  // a conditional pass books no bytes
       LAUNCH_BEGIN();
+      const bool decides = dec && c0 == 0;
       launch_dots(c->stream, vec_ptr(s, b->cap, b->nq, src_ref), tt, colset(s, first + v0 * stride, stride, v1 - v0, qfirst + q0, q1 - q0),
-                  s.nd, s.partials + (int64_t)c0 * b->es * s.pstride, s.pstride, s.g_vec, ctl, b->es == 2);
+                  s.nd, s.partials + (int64_t)c0 * b->es * s.pstride, s.pstride, s.g_vec, decides ? s.ctrl : ctl, b->es == 2, nullptr, nullptr,
+                  nullptr, decides ? dec : nullptr);
       LAUNCHCHK("k_dots");
     }
+    if (skip_reduce) continue;
     ProfScope ps(c, EIGENEX_K_SMALL, 0.0);
     launch_reduce(c->stream, s.partials, s.pstride, s.g_vec, ncols * b->es, s.hbuf + base + slot * b->es, ctl);
   }
@@ -1186,8 +1194,12 @@ inline bool decides_locally(const eigenex_basis_s* b) { return b->ctx->P == 1 &&
 
 // fin_mode >= 0 (a FinNormMode; only with want_norm, the state's control block and decides_locally): the norm's
 // second-stage sum also takes the step decision
+// norm_to_pnorm (one shard): the ||dst||^2 partial sums go to the hand-over buffer pnorm instead of the dots partials' buffer (a
+// consumer kernel adds them itself while the next dots pass is already writing its partials); reduce_inline: the second-stage
+// sums of the preceding dots pass are formed inside the kernel (InlineReduce) -- the caller has skipped k_reduce
 int enq_update(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_term, int k, int first, int stride, int count,
-               int qfirst, int nq, int slot, bool want_norm, int use_ctrl, int base = 0, int nrm_slot = -1, int fin_mode = -1) {
+               int qfirst, int nq, int slot, bool want_norm, int use_ctrl, int base = 0, int nrm_slot = -1, int fin_mode = -1,
+               bool norm_to_pnorm = false, bool reduce_inline = false) {
   if (nrm_slot < 0) nrm_slot = b->slot_nrm();
   eigenex_context_s* c = b->ctx;
   const int ncols = count + nq;
@@ -1198,9 +1210,10 @@ int enq_update(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_term, in
     {
       ProfScope ps(c, EIGENEX_K_UPDATE, use_ctrl == 2 ? 0.0 : 8.0 * s.nd * ncols + 24.0 * s.nd + (three_term ? 32.0 * s.nd : 0.0));
       LAUNCH_BEGIN();
+      const InlineReduce red{s.partials, s.pstride, s.g_vec, ncols * b->es, s.hbuf + base + slot * b->es};
       launch_update(c->stream, vec_ptr(s, b->cap, b->nq, src_ref), vec_ptr(s, b->cap, b->nq, dst_ref), tt,
-                    colset(s, first, stride, count, qfirst, nq), s.hbuf + base + slot * b->es, s.nd, s.partials, s.g_vec, ctl,
-                    b->es == 2);
+                    colset(s, first, stride, count, qfirst, nq), s.hbuf + base + slot * b->es, s.nd, norm_to_pnorm ? s.pnorm : s.partials, s.g_vec, ctl,
+                    b->es == 2, reduce_inline ? &red : nullptr);
       LAUNCHCHK("k_update");
     }
     if (want_norm) {
@@ -1224,25 +1237,41 @@ int enq_update(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_term, in
 // stage (*fin_merged = true) the caller must not launch k_fin_norm itself
 int enq_orthogonalize(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_term, int k, int first, int stride,
                       int count, int nq, bool q_first, bool norm_before = false, int fin_mode = -1, bool* fin_merged = nullptr,
-                      bool fused_alpha = false, bool before_in_palpha = false) {
+                      bool fused_alpha = false, bool before_in_palpha = false, bool defer_tail = false) {
   const int merge = (fin_mode >= 0 && fin_merged && decides_locally(b)) ? fin_mode : -1;
   if (fin_merged) *fin_merged = false;
   int mode = b->ortho_mode;
   if (mode == EIGENEX_ORTHO_BATCHED_ADAPTIVE && (three_term || count + nq == 0)) mode = EIGENEX_ORTHO_BATCHED;
   if (mode == EIGENEX_ORTHO_BATCHED_ADAPTIVE && !norm_before) mode = EIGENEX_ORTHO_BATCHED_TWICE;
   if (mode == EIGENEX_ORTHO_BATCHED_ADAPTIVE && fin_mode == kFinArnoldi && fin_merged && decides_locally(b)) {
-    // one shard: the tiny launches around the conditional second pass are merged (k_reduce_decide, k_arnoldi_tail);
-    // the caller launches neither k_fin_norm nor k_arnoldi_end
+    // one shard: the tiny launches around the conditional second pass are taken by their consumers (r3: 12 -> 10 -> 6/7 launches
+    // per step): the decision by the second pass's dots kernel (InlineDecide), that pass's second-stage sums by its update kernel
+    // (InlineReduce), the end of the step (k_arnoldi_tail) by the NEXT step's operator kernel (InlineArnoldiBegin.tail_k) unless
+    // this is the last call of a batch or the next call cannot take it.  The caller launches neither k_fin_norm nor k_arnoldi_end.
     hipStream_t st = b->ctx->stream;
     BasisShard& s = b->sh[0];
+    const int ncoef = (count + nq) * b->es;
+    const bool inline_small = ncoef <= kInlineReduceMaxCoef && std::getenv("EIGENEX_NO_INLINE_FIN") == nullptr;
     CHK(enq_dots(b, src_ref, false, 0, first, stride, count, 0, nq, 0, 1));
-    CHK(enq_update(b, src_ref, dst_ref, false, 0, first, stride, count, 0, nq, 0, false, 1));
-    launch_reduce_decide(st, s.partials, s.g_vec, s.hbuf + b->slot_nrm_first(), s.ctrl, s.ctrl_pass2, s.hbuf + b->slot_nrm_before(), 0.5,
-                         before_in_palpha ? s.palpha : nullptr, s.g_spmv);
-    CHK(enq_dots(b, dst_ref, false, 0, first, stride, count, 0, nq, 0, 2, b->base_h2()));
-    CHK(enq_update(b, dst_ref, dst_ref, false, 0, first, stride, count, 0, nq, 0, false, 2, b->base_h2()));
-    launch_arnoldi_tail(st, s.partials, s.g_vec, s.ctrl, s.ctrl_pass2, s.hbuf, s.hbuf + b->base_h2(), (count + nq) * b->es,
-                        s.hbuf + b->slot_nrm_first(), s.hbuf + b->slot_nrm(), s.H, b->ldh, b->es);
+    CHK(enq_update(b, src_ref, dst_ref, false, 0, first, stride, count, 0, nq, 0, false, 1, 0, -1, -1, /*norm_to_pnorm=*/true));
+    if (inline_small) {
+      const InlineDecide dec{s.ctrl_pass2, s.pnorm, s.g_vec, before_in_palpha ? s.palpha : nullptr, s.g_spmv, 0.5,
+                             s.hbuf + b->slot_nrm_first(), s.hbuf + b->slot_nrm_before()};
+      CHK(enq_dots(b, dst_ref, false, 0, first, stride, count, 0, nq, 0, 2, b->base_h2(), &dec, /*skip_reduce=*/true));
+      CHK(enq_update(b, dst_ref, dst_ref, false, 0, first, stride, count, 0, nq, 0, false, 2, b->base_h2(), -1, -1, true, /*reduce_inline=*/true));
+    } else {
+      launch_reduce_decide(st, s.pnorm, s.g_vec, s.hbuf + b->slot_nrm_first(), s.ctrl, s.ctrl_pass2, s.hbuf + b->slot_nrm_before(), 0.5,
+                           before_in_palpha ? s.palpha : nullptr, s.g_spmv);
+      CHK(enq_dots(b, dst_ref, false, 0, first, stride, count, 0, nq, 0, 2, b->base_h2()));
+      CHK(enq_update(b, dst_ref, dst_ref, false, 0, first, stride, count, 0, nq, 0, false, 2, b->base_h2(), -1, -1, true));
+    }
+    if (defer_tail && inline_small) {
+      b->tail_pending = true;
+      b->tail_ncoef = ncoef;
+    } else {
+      launch_arnoldi_tail(st, s.pnorm, s.g_vec, s.ctrl, s.ctrl_pass2, s.hbuf, s.hbuf + b->base_h2(), ncoef,
+                          s.hbuf + b->slot_nrm_first(), s.hbuf + b->slot_nrm(), s.H, b->ldh, b->es);
+    }
     *fin_merged = true;
     return 0;
   }
@@ -1600,7 +1629,7 @@ int lanczos_call(eigenex_basis_s* b, bool last_in_batch) {
 }
 
 // one call of ArnoldiBase::updateArnoldiSteps()  (arnoldi.hpp:312-392)
-int arnoldi_call(eigenex_basis_s* b) {
+int arnoldi_call(eigenex_basis_s* b, bool last_in_batch) {
   hipStream_t st = b->ctx->stream;
   int k;
   bool begin_inline = false;
@@ -1610,9 +1639,15 @@ int arnoldi_call(eigenex_basis_s* b) {
     k = 0;
   } else {
     k = b->h_nvec;
-    if (k >= b->cap && (int64_t)k < b->n_global) return fail(EIGENEX_ERR_STATE, "basis capacity exhausted");
     // :357-365.  One shard with an operator kernel that has the hook: the operator kernel does this itself (one launch less)
     begin_inline = k < b->cap && inline_begin_ok(b);
+    if (b->tail_pending && !begin_inline) {  // (cannot happen: a tail is only left behind when the next call can take it)
+      BasisShard& s = b->sh[0];
+      launch_arnoldi_tail(st, s.pnorm, s.g_vec, s.ctrl, s.ctrl_pass2, s.hbuf, s.hbuf + b->base_h2(), b->tail_ncoef,
+                          s.hbuf + b->slot_nrm_first(), s.hbuf + b->slot_nrm(), s.H, b->ldh, b->es);
+      b->tail_pending = false;
+    }
+    if (k >= b->cap && (int64_t)k < b->n_global) return fail(EIGENEX_ERR_STATE, "basis capacity exhausted");
     if (!begin_inline)
       for (auto& s : b->sh) launch_arnoldi_begin(st, s.ctrl, b->threshold, b->n_global, b->cap, s.H, b->ldh, b->es);
     if (k >= b->cap) return 0;  // full Krylov space: the begin kernel has recorded "returned false"
@@ -1620,16 +1655,24 @@ int arnoldi_call(eigenex_basis_s* b) {
   const bool adaptive = b->ortho_mode == EIGENEX_ORTHO_BATCHED_ADAPTIVE && b->csr != nullptr;
   // one shard that decides locally: ||v||^2 stays as the operator's partial sums until k_reduce_decide (one launch less)
   const bool small_merged = adaptive && decides_locally(b);
-  const InlineArnoldiBegin ab{b->sh[0].ctrl, b->threshold, b->n_global, b->cap, b->sh[0].H, b->ldh, b->es};
+  BasisShard& s0 = b->sh[0];
+  const bool take_tail = begin_inline && b->tail_pending;  // the previous call left its end to this call's operator kernel
+  const InlineArnoldiBegin ab{s0.ctrl, b->threshold, b->n_global, b->cap, s0.H, b->ldh, b->es,
+                              take_tail ? k - 1 : -1, s0.pnorm, s0.g_vec, s0.ctrl_pass2, s0.hbuf, s0.hbuf + b->base_h2(), b->tail_ncoef,
+                              s0.hbuf + b->slot_nrm_first(), s0.hbuf + b->slot_nrm()};
+  b->tail_pending = false;
   CHK(enq_apply(b, k, false, adaptive, -1, nullptr, false, small_merged, begin_inline ? &ab : nullptr));  // :333-336, :369-372
   if (!b->csr && b->shift != 0.0) { /* shift applied inside enq_apply's host path */ }
   // :337-345, :373-383
   bool tail_done = false;  // only the adaptive scheme on one shard folds k_fin_norm and k_arnoldi_end into its last launch
-  if (adaptive)
+  if (adaptive) {
+    // the end of this step can wait for the next call's operator kernel if there will be one in this batch that has the hook
+    const bool defer_tail = small_merged && !last_in_batch && k + 1 < b->cap && (int64_t)(k + 1) < b->n_global && inline_begin_ok(b);
     CHK(enq_orthogonalize(b, EIGENEX_VEC_V, EIGENEX_VEC_W, false, 0, 0, 1, k + 1, b->nq, true, true, kFinArnoldi, &tail_done, false,
-                          small_merged));
-  else
+                          small_merged, defer_tail));
+  } else {
     CHK(enq_orthogonalize(b, EIGENEX_VEC_V, EIGENEX_VEC_W, false, 0, 0, 1, k + 1, b->nq, true));
+  }
   if (!tail_done)
     for (auto& s : b->sh) {
       launch_fin_norm(st, s.ctrl, s.hbuf + b->slot_nrm(), b->threshold, kFinArnoldi, s.beta);  // :348, :385
@@ -1706,7 +1749,7 @@ void drop_step_graphs(eigenex_basis_s* b) {
 
 int enqueue_steps(eigenex_basis_s* b, int ncalls, int kind) {
   auto plain = [&]() -> int {
-    for (int i = 0; i < ncalls; ++i) CHK(kind == 0 ? lanczos_call(b, i == ncalls - 1) : arnoldi_call(b));
+    for (int i = 0; i < ncalls; ++i) CHK(kind == 0 ? lanczos_call(b, i == ncalls - 1) : arnoldi_call(b, i == ncalls - 1));
     return 0;
   };
   eigenex_context_s* c = b->ctx;
@@ -2810,6 +2853,7 @@ int eigenex_basis_clear(eigenex_basis_t b) {
   b->started = false;
   b->h_nvec = 0;
   b->alpha_pending = b->alpha_pending_inline = false;
+  b->tail_pending = false;
   return 0;
 }
 
