@@ -16,7 +16,7 @@ L1="TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_s
 scripts/profile_passes.sh headline "FETCH_SIZE;WRITE_SIZE" python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline || exit $?
 scripts/profile_passes.sh config3 "FETCH_SIZE;WRITE_SIZE;$L2;$L1" python3 scripts/run_config3.py 1000000 80 2 || exit $?
 PASS_TIMEOUT=600 scripts/profile_passes.sh config5 "FETCH_SIZE;WRITE_SIZE;$L2" python3 scripts/run_config5.py 20000000 10 4 6 || exit $?
-run() { echo "== $*"; timeout -k 10 500 "$@" || exit $?; }
+run() { echo "== $*" >&2; timeout -k 10 500 "$@" || exit $?; }
 run python3 bench.py --steps 5 --warmup 2 > gpurun_out/${RND}_bench.json 2> gpurun_out/${RND}_bench.err
 run python3 bench.py --grid-edge 128 --krylov-steps 50 --steps 20 --warmup 5 > gpurun_out/${RND}_bench_128cubed.json 2> gpurun_out/${RND}_bench_128cubed.err
 run python3 bench.py --workload config3 --steps 5 --warmup 2 > gpurun_out/${RND}_bench_config3.json 2> gpurun_out/${RND}_bench_config3.err
