@@ -58,6 +58,8 @@ def parse_args(argv=None):
     ap.add_argument("--krylov-steps", "--m", dest="m", type=int, default=100, help="Lanczos iterations per solve")
     ap.add_argument("--sequential", action="store_true", help="reference-order sequential Gram-Schmidt instead of batched")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--halo-overlap", action="store_true",
+                    help="N > 1: neighbour exchange on a second stream / communicator beside the interior rows (opt-in between real ranks)")
     ap.add_argument("--workload", choices=("laplacian", "config3", "config1"), default="laplacian",
                     help="laplacian (default): the BASELINE metric's workload (configs 2/4 by --grid-edge/--krylov-steps); config3: random "
                          "CSR 10^6 x 32, Arnoldi m=80; config1: dense 512 x 512, Lanczos lowest five pairs through the host callback "
@@ -433,6 +435,7 @@ def main():
     ctx = capi.Context(device=dev_index, rank=rank, world_size=world, rccl_id=rccl_id)
     if multi_path and not ctx.rccl_selftest():
         sys.exit(f"rank {rank}: RCCL self-test (all-reduce / all-gather / send-recv ring) returned wrong data")
+    halo_overlap = ctx.set_halo_overlap(True) if (multi_path and args.halo_overlap) else False  # collective: every rank calls it
     A = capi.Csr.laplacian3d(ctx, n)
     # same global start vector on every rank, as in the reference API where initialVector has matrixHeight entries:
     # the reference's default (std::mt19937 default seed, std::normal_distribution, normalised; lanczos.hpp:214-218,
@@ -499,6 +502,7 @@ def main():
         per_launch_update = tab[:, 7] / np.maximum(tab[:, 10], 1)
         multi = {
             "rccl_ranks": int(tab[0, 0]),
+            "halo_overlap": bool(halo_overlap),
             "rccl_rank_of_each_process": [int(x) for x in tab[:, 1]],
             "device_of_each_rank": [int(x) for x in tab[:, 2]],
             "rows_per_rank": [int(x) for x in tab[:, 3]],

@@ -2101,12 +2101,17 @@ int eigenex_context_create(int device, int rank, int world_size, const void* rcc
       delete c;
       return fail(EIGENEX_ERR_RCCL, m);
     }
-    // a communicator of its own for the neighbour exchange, so that it may run on the halo stream beside the all-reduces of the
-    // compute stream (one communicator's operations must be issued in one order).  If it cannot be had, the exchange stays where it was.
-    if (ncclCommSplit(c->comm, 0, rank, &c->comm_halo, nullptr) != ncclSuccess) c->comm_halo = nullptr;
-    (void)hipGetLastError();
   }
-  c->halo_overlap = c->comm_halo != nullptr && std::getenv("EIGENEX_NO_HALO_OVERLAP") == nullptr;
+  // Between real ranks the overlapped exchange is OPT-IN (EIGENEX_HALO_OVERLAP=1 or eigenex_context_set_halo_overlap): it needs a second
+  // communicator and runs two communicators' kernels side by side, which no box of this pool could exercise (one GPU each); the
+  // default multi-rank step is the schedule that the loopback tests prove equivalent, with the exchange in front of the operator.
+  if (c->comm && std::getenv("EIGENEX_HALO_OVERLAP") != nullptr) {
+    const int rc2 = eigenex_context_set_halo_overlap(c, 1);
+    if (rc2 < 0) {
+      eigenex_context_destroy(c);
+      return rc2;
+    }
+  }
   *out = c;
   return 0;
 }
@@ -2199,6 +2204,13 @@ int eigenex_context_set_halo_overlap(eigenex_context_t c, int on) {
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipStreamSynchronize(c->stream_halo));
+  if (on && c->comm && !c->comm_halo) {
+    // a communicator of its own for the neighbour exchange, so that it may run on the halo stream beside the all-reduces of the
+    // compute stream (one communicator's operations must be issued in one order).  COLLECTIVE: every rank must make this call.
+    // If it cannot be had, the exchange stays where it was.
+    if (ncclCommSplit(c->comm, 0, c->rank, &c->comm_halo, nullptr) != ncclSuccess) c->comm_halo = nullptr;
+    (void)hipGetLastError();
+  }
   c->halo_overlap = on != 0 && c->P > 1 && (c->loopback || c->comm_halo != nullptr);
   return c->halo_overlap ? 1 : 0;
 }

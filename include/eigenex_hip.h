@@ -160,7 +160,9 @@ int eigenex_context_info(eigenex_context_t ctx, int* rank, int* world_size, int*
  * operator is applied to the 256-row tiles that read no halo column; the tiles that do wait for it.  on = 0 puts the exchange
  * back in front of the operator on the compute stream: the same launches and the same bits, for comparison.  Returns 1 if the
  * overlap is on afterwards, 0 if off (also when asked for but unavailable: one shard, or no second communicator), < 0 on
- * error.  Default: on where available; EIGENEX_NO_HALO_OVERLAP=1 in the environment turns the default off. */
+ * error.  Between real ranks the first call with on != 0 creates the second communicator: it is COLLECTIVE (every rank
+ * must make it).  Default: on for loopback contexts (EIGENEX_NO_HALO_OVERLAP=1 turns that off), OFF between real ranks
+ * unless EIGENEX_HALO_OVERLAP=1 is set when the context is created. */
 int eigenex_context_set_halo_overlap(eigenex_context_t ctx, int on);
 /* what the RCCL communicator itself reports (ncclCommCount / ncclCommUserRank / ncclCommCuDevice): *comm_ranks = 0
  * when the context has no communicator (single GPU, loopback) */
