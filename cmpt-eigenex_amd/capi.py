@@ -85,6 +85,7 @@ SIGNATURES = {
     "eigenex_profile_get": (C.c_int, [_vp, C.c_int, _lp, _dp, _dp]),
     "eigenex_csr_upload": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int64, _ip, _ip, _dp, C.POINTER(_vp)]),
     "eigenex_csr_upload_z": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int64, _ip, _ip, _dp, C.POINTER(_vp)]),
+    "eigenex_csr_upload64": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int64), _ip, _dp, C.POINTER(_vp)]),
     "eigenex_csr_laplacian3d": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp)]),
     "eigenex_csr_destroy": (C.c_int, [_vp]),
     "eigenex_csr_upload_ex": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int64, _ip, _ip, _dp, C.c_int, C.c_int, C.POINTER(_vp)]),
@@ -404,6 +405,17 @@ class Csr:
         obj = cls(ctx, h)
         obj.is_complex = bool(np.iscomplexobj(val))
         return obj
+
+    @classmethod
+    def upload64(cls, ctx: Context, n_global: int, rowptr, col, val, row_begin: int = 0):
+        """eigenex_csr_upload64: real CSR with 64-bit row pointers (shards of >= 2^31 stored entries are kept as plain CSR with
+        64-bit row pointers on the device, smaller ones exactly as `upload` stores them)."""
+        rp = np.ascontiguousarray(rowptr, np.int64)
+        cl = np.ascontiguousarray(col, np.int32)
+        vl = np.ascontiguousarray(val, np.float64)
+        h = _vp()
+        _chk(lib().eigenex_csr_upload64(ctx.h, n_global, row_begin, rp.size - 1, rp.ctypes.data_as(C.POINTER(C.c_int64)), _i(cl), _d(vl), C.byref(h)))
+        return cls(ctx, h)
 
     @classmethod
     def from_device(cls, ctx: Context, n: int, rowptr_ptr: int, col_ptr: int, val_ptr: int, is_complex: bool = False):

@@ -706,19 +706,19 @@ bool build_sorted_layout_t(const CsrShard& s, const std::vector<int32_t>& lcol, 
 
 // The host-only half of a row shard: ranges, halo slots, local column numbering, receive segments.  No device call:
 // eigenex_plan_create exposes exactly this to hosts without a GPU (the gloo tests drive it across real processes).
-int plan_shard_host(int64_t n_global, int P, int gshard, const int32_t* rowptr, const int32_t* col, int es, CsrShard& s,
-                    std::vector<int32_t>& lcol) {
+// col: the shard's stored entries (already offset to its first one), nnz of them; may exceed 2^31 (64-bit row pointers)
+int plan_shard_entries(int64_t n_global, int P, int gshard, int64_t nnz, const int32_t* col, int es, CsrShard& s,
+                       std::vector<int32_t>& lcol) {
   s.gshard = gshard;
   s.es = es;
   partition(n_global, P, gshard, &s.rb, &s.re);
   s.nloc = s.re - s.rb;
   s.npad = pad_rows(s.nloc);
-  const int64_t p0 = rowptr[0];
-  s.nnz = (int64_t)rowptr[s.nloc] - p0;
-  if (s.nnz < 0 || s.nnz > (int64_t)2147483647 - 16384) return fail(EIGENEX_ERR_ARG, "nnz of a shard must be < 2^31 - 16384");
+  s.nnz = nnz;
+  if (s.nnz < 0) return fail(EIGENEX_ERR_ARG, "row pointers decrease");
   std::vector<int32_t> rem;
   for (int64_t p = 0; p < s.nnz; ++p) {
-    const int64_t cg = col[p0 + p];
+    const int64_t cg = col[p];
     if (cg < 0 || cg >= n_global) return fail(EIGENEX_ERR_ARG, "column index out of range");
     if (cg < s.rb || cg >= s.re) rem.push_back((int32_t)cg);
   }
@@ -729,14 +729,56 @@ int plan_shard_host(int64_t n_global, int P, int gshard, const int32_t* rowptr, 
   if (s.npad + s.nhalo > 2147483647) return fail(EIGENEX_ERR_ARG, "local + halo columns exceed int32");
   lcol.assign((size_t)s.nnz + 8, 0);
   for (int64_t p = 0; p < s.nnz; ++p) {
-    const int64_t cg = col[p0 + p];
+    const int64_t cg = col[p];
     if (cg >= s.rb && cg < s.re)
-      lcol[p] = (int32_t)(cg - s.rb);
+      lcol[(size_t)p] = (int32_t)(cg - s.rb);
     else
-      lcol[p] = (int32_t)(s.npad + (std::lower_bound(s.halo_cols.begin(), s.halo_cols.end(), (int32_t)cg) -
-                                    s.halo_cols.begin()));
+      lcol[(size_t)p] = (int32_t)(s.npad + (std::lower_bound(s.halo_cols.begin(), s.halo_cols.end(), (int32_t)cg) -
+                                            s.halo_cols.begin()));
   }
   build_recv(s, n_global, P);
+  return 0;
+}
+
+int plan_shard_host(int64_t n_global, int P, int gshard, const int32_t* rowptr, const int32_t* col, int es, CsrShard& s,
+                    std::vector<int32_t>& lcol) {
+  int64_t rb, re;
+  partition(n_global, P, gshard, &rb, &re);
+  const int64_t p0 = rowptr[0], nnz = (int64_t)rowptr[re - rb] - p0;
+  if (nnz < 0 || nnz > (int64_t)2147483647 - 16384) return fail(EIGENEX_ERR_ARG, "nnz of a shard must be < 2^31 - 16384 (eigenex_csr_upload64 takes 64-bit row pointers)");
+  return plan_shard_entries(n_global, P, gshard, nnz, col + p0, es, s, lcol);
+}
+
+// A shard whose stored entries need 64-bit row pointers (eigenex_csr_upload64; r3): plain real CSR in one pass, rowptr64 rebased to
+// the shard's first entry, col in local numbering (int32), the interior / boundary tile lists between shards.  rowptr: the shard's
+// nloc + 1 entries of the caller's array.
+int build_shard_host_wide(eigenex_context_s* c, int64_t n_global, int gshard, const int64_t* rowptr, const int32_t* col,
+                          const double* val, CsrShard& s) {
+  int64_t rb, re;
+  partition(n_global, c->P, gshard, &rb, &re);
+  const int64_t nloc = re - rb, p0 = rowptr[0];
+  std::vector<int32_t> lcol;
+  CHK(plan_shard_entries(n_global, c->P, gshard, rowptr[nloc] - p0, col + p0, 1, s, lcol));
+  std::vector<int64_t> lrp((size_t)nloc + 1);
+  for (int64_t i = 0; i <= nloc; ++i) lrp[(size_t)i] = rowptr[i] - p0;
+  if (c->P > 1 && nloc > 0) {
+    std::vector<uint8_t> bnd((size_t)((nloc + kSpmvRows - 1) / kSpmvRows), 0);
+    for (int64_t r = 0; r < nloc; ++r)
+      for (int64_t p = lrp[(size_t)r]; p < lrp[(size_t)r + 1]; ++p)
+        if (lcol[(size_t)p] >= s.npad) {
+          bnd[(size_t)(r / kSpmvRows)] = 1;
+          break;
+        }
+    CHK(upload_tile_lists(c, s, bnd));
+  }
+  HIPCHK(hipMalloc(&s.rowptr64, sizeof(int64_t) * (size_t)(nloc + 1)));
+  HIPCHK(hipMalloc(&s.col, sizeof(int32_t) * (size_t)(s.nnz + kCsrTailPad)));
+  HIPCHK(hipMalloc(&s.val, sizeof(double) * (size_t)(s.nnz + kCsrTailPad)));
+  HIPCHK(hipMemsetAsync(s.val + s.nnz, 0, sizeof(double) * kCsrTailPad, c->stream));
+  HIPCHK(hipMemcpyAsync(s.rowptr64, lrp.data(), sizeof(int64_t) * (size_t)(nloc + 1), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(s.col, lcol.data(), sizeof(int32_t) * (size_t)(s.nnz + kCsrTailPad), hipMemcpyHostToDevice, c->stream));
+  if (s.nnz) HIPCHK(hipMemcpyAsync(s.val, val + p0, sizeof(double) * (size_t)s.nnz, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
 
@@ -2305,6 +2347,52 @@ static int csr_upload_impl(eigenex_context_t c, int64_t n_global, int64_t row_be
 int eigenex_csr_upload(eigenex_context_t c, int64_t n_global, int64_t row_begin, int64_t n_rows, const int32_t* rowptr,
                        const int32_t* col_global, const double* val, eigenex_csr_t* out) {
   return csr_upload_impl(c, n_global, row_begin, n_rows, rowptr, col_global, val, 1, -1, out);
+}
+
+// 64-bit row pointers (the reference's Index, lanczos.hpp:108-116): a shard may hold >= 2^31 stored entries.  Shards below that
+// go through eigenex_csr_upload's path (every layout available), the others are stored as plain CSR with 64-bit row pointers.
+int eigenex_csr_upload64(eigenex_context_t c, int64_t n_global, int64_t row_begin, int64_t n_rows, const int64_t* rowptr,
+                         const int32_t* col_global, const double* val, eigenex_csr_t* out) {
+  if (!c || !out || !rowptr || n_global <= 0 || n_rows < 0) return fail(EIGENEX_ERR_ARG, "eigenex_csr_upload64: bad argument");
+  if (n_rows > 0 && rowptr[n_rows] > rowptr[0] && (!col_global || !val)) return fail(EIGENEX_ERR_ARG, "col/val is NULL");
+  HIPCHK(hipSetDevice(c->device));
+  int64_t fb, fe, lb, le;
+  partition(n_global, c->P, c->local.front(), &fb, &fe);
+  partition(n_global, c->P, c->local.back(), &lb, &le);
+  if (row_begin != fb || row_begin + n_rows != le)
+    return fail(EIGENEX_ERR_ARG, "rows passed do not match eigenex_partition for this context");
+  if (rowptr[0] < 0) return fail(EIGENEX_ERR_ARG, "row pointers must be non-negative");
+  for (int64_t i = 0; i < n_rows; ++i)
+    if (rowptr[i + 1] < rowptr[i]) return fail(EIGENEX_ERR_ARG, "row pointers are not non-decreasing");
+  auto* m = new eigenex_csr_s();
+  m->ctx = c;
+  m->n_global = n_global;
+  m->es = 1;
+  m->sh.resize(c->local.size());
+  const bool force_wide = std::getenv("EIGENEX_FORCE_WIDE_ROWPTR") != nullptr;
+  int rc = 0;
+  for (size_t i = 0; i < c->local.size() && !rc; ++i) {
+    int64_t rb, re;
+    partition(n_global, c->P, c->local[i], &rb, &re);
+    const int64_t* rp = rowptr + (rb - row_begin);
+    const int64_t p0 = rp[0], nnz = rp[re - rb] - p0;
+    if (!force_wide && nnz <= (int64_t)2147483647 - 16384) {
+      std::vector<int32_t> rp32((size_t)(re - rb) + 1);
+      for (int64_t k = 0; k <= re - rb; ++k) rp32[(size_t)k] = (int32_t)(rp[k] - p0);
+      rc = build_shard_host(c, n_global, c->local[i], rp32.data(), col_global + p0, val + p0, 1, -1, m->sh[i]);
+    } else {
+      rc = build_shard_host_wide(c, n_global, c->local[i], rp, col_global, val, m->sh[i]);
+    }
+  }
+  if (!rc && c->P > 1) rc = c->loopback ? build_send_lists_loopback(c, m) : exchange_send_lists_rccl(c, n_global, m->sh[0]);
+  if (rc) {
+    std::string keep = g_err;
+    eigenex_csr_destroy(m);
+    g_err = keep;
+    return rc;
+  }
+  *out = m;
+  return 0;
 }
 
 // CSR already in device memory (e.g. a torch tensor's data_ptr()): device-to-device copy into the library's padded

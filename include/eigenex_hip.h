@@ -195,6 +195,12 @@ int eigenex_csr_upload(eigenex_context_t ctx, int64_t n_global, int64_t row_begi
 int eigenex_csr_upload_z(eigenex_context_t ctx, int64_t n_global, int64_t row_begin, int64_t n_rows,
                          const int32_t* rowptr, const int32_t* col_global, const double* val_interleaved,
                          eigenex_csr_t* out);
+/* r3 -- the same with 64-bit row pointers: the reference's Index is 64-bit (lanczos.hpp:108-116), and one MI355X holds shards
+ * of more than 2^31 stored entries (768^3: 3.2e9).  Real operators.  Shards below 2^31 - 16384 entries are stored exactly as
+ * eigenex_csr_upload stores them (automatic layout included); larger ones as plain CSR with 64-bit row pointers on the
+ * device (column indices stay 32-bit: local numbering).  Stands behind setMatrixMultiplication (lanczos.hpp:179) like the others. */
+int eigenex_csr_upload64(eigenex_context_t ctx, int64_t n_global, int64_t row_begin, int64_t n_rows, const int64_t* rowptr,
+                         const int32_t* col_global, const double* val, eigenex_csr_t* out);
 /* Upload with an explicit column-blocking choice.  A column-blocked operator is applied in K passes, pass k
  * holding the entries whose column lies in the k-th slice of the operator input, so that a slice (<= ~2 MB) stays
  * in each XCD's L2 while it is gathered from: 1.5x on a random 32-per-row matrix of 10^6 rows (BASELINE config 3),

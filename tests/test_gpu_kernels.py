@@ -818,3 +818,41 @@ def test_wide_row_pointers_change_nothing(capi, monkeypatch):
     for shards in (1, 3):
         np.testing.assert_array_equal(out[(True, shards)][0], out[(False, shards)][0])
         np.testing.assert_array_equal(out[(True, shards)][1], out[(False, shards)][1])
+
+
+@pytest.mark.parametrize("shards", [1, 3])
+def test_upload_with_64_bit_row_pointers(capi, monkeypatch, shards):
+    """eigenex_csr_upload64: host CSR with 64-bit row pointers.  Small shards are stored exactly as eigenex_csr_upload stores
+    them (same automatic layout, same bits); forced onto the 64-bit device path (EIGENEX_FORCE_WIDE_ROWPTR) the operator output is
+    still the oracle's row loop bit for bit and the Lanczos coefficients those of the 32-bit run -- heavy-tailed rows over several
+    chunks, empty rows, scattered halo columns, malformed input refused."""
+    from structures import random_structure
+
+    n, rowptr, col, val, x, counts, _, _ = random_structure(4)  # kind 1: heavy tail
+    y_ref = cref.csr_spmv(rowptr, col, val, x)
+    res = {}
+    for mode in ("upload", "upload64", "upload64 wide"):
+        if mode.endswith("wide"):
+            monkeypatch.setenv("EIGENEX_FORCE_WIDE_ROWPTR", "1")
+        else:
+            monkeypatch.delenv("EIGENEX_FORCE_WIDE_ROWPTR", raising=False)
+        ctx = capi.Context(loopback_shards=shards) if shards > 1 else capi.Context()
+        A = capi.Csr.upload(ctx, n, rowptr, col, val, column_blocks=0) if mode == "upload" else capi.Csr.upload64(ctx, n, rowptr.astype(np.int64), col, val)
+        b = capi.Basis(ctx, A, n, 8)
+        b.upload(capi.VEC_W, x)
+        b.apply(capi.VEC_W, capi.VEC_V, 0.0)
+        np.testing.assert_array_equal(b.download(capi.VEC_V), y_ref)
+        b.upload(capi.VEC_W, x)
+        b.arnoldi_enqueue(6)
+        st, H = b.arnoldi_state()
+        res[mode] = H.copy()
+        b.close()
+        A.close()
+        if mode == "upload64":
+            bad = rowptr.astype(np.int64)
+            bad[3] = bad[2] - 1
+            with pytest.raises(capi.EigenexError):
+                capi.Csr.upload64(ctx, n, bad, col, val)
+        ctx.close()
+    np.testing.assert_array_equal(res["upload64 wide"], res["upload"])
+    np.testing.assert_array_equal(res["upload64"], res["upload"])
