@@ -80,6 +80,12 @@ class CsrOperator {
       : ctx_(std::move(ctx)), n_(n_global) {
     check(eigenex_csr_upload(ctx_->handle(), n_global, row_begin, n_rows, rowptr, col_global, val, &h_), "eigenex_csr_upload");
   }
+  // 64-bit row pointers (the reference's Index, lanczos.hpp:108-116): a shard may hold >= 2^31 stored entries (eigenex_csr_upload64)
+  CsrOperator(std::shared_ptr<Context> ctx, std::int64_t n_global, std::int64_t row_begin, std::int64_t n_rows,
+              const std::int64_t* rowptr, const std::int32_t* col_global, const double* val)
+      : ctx_(std::move(ctx)), n_(n_global) {
+    check(eigenex_csr_upload64(ctx_->handle(), n_global, row_begin, n_rows, rowptr, col_global, val, &h_), "eigenex_csr_upload64");
+  }
   // complex values (std::complex<double>, crossing the C ABI as interleaved doubles)
   static std::shared_ptr<CsrOperator> complexCsr(std::shared_ptr<Context> ctx, std::int64_t n_global, std::int64_t row_begin,
                                                  std::int64_t n_rows, const std::int32_t* rowptr,

@@ -48,6 +48,16 @@ int main() {
     for (Index i = 0; i < dev.eigenvalues().size(); ++i) std::printf("%s%.17g", i ? ", " : "", dev.eigenvalues()[i]);
     std::printf("], \"subspace\": %ld}, ", (long)dev.lanczosvectors().size());
 
+    // the same CSR with the reference's 64-bit Index as row-pointer type (eigenex_csr_upload64): identical results
+    std::vector<std::int64_t> rowptr64(rowptr.begin(), rowptr.end());
+    auto op64 = std::make_shared<device::CsrOperator>(ctx, n, 0, n, rowptr64.data(), col.data(), val.data());
+    LanczosEigenSolver<double> dev64;
+    dev64.setDeviceOperator(op64).setTolerance(1.0e-5).setMaxIterations(100);
+    dev64.compute();
+    bool same64 = dev64.eigenvalues().size() == dev.eigenvalues().size();
+    for (Index i = 0; same64 && i < dev.eigenvalues().size(); ++i) same64 = dev64.eigenvalues()[i] == dev.eigenvalues()[i];
+    std::printf("\"device_operator_index64_identical\": %s, ", same64 ? "true" : "false");
+
     // the sample's own operator storage: the dense matrix itself on the device (device::denseOperator)
     DenseMatrix<double> Hd(n, n);
     for (int r = 0; r < n; ++r)

@@ -77,6 +77,7 @@ def test_cpp_program_against_reference_sample(golden_dir, tmp_path):
     np.testing.assert_allclose(H @ X, X * np.array(gold["eigenvalues"]), atol=1e-12)
     assert np.all(X[0] > 0)
     assert out["device_operator"]["subspace"] == 3
+    assert out["device_operator_index64_identical"] is True  # CsrOperator from std::int64_t row pointers (eigenex_csr_upload64)
     assert out["arnoldi"]["n"] == 3 and out["arnoldi"]["max_residual"] < 1e-12
 
 
