@@ -77,7 +77,7 @@ def _runs(capi, ctx, world, rank, n_lap, n_rand, m):
     return out
 
 
-def _worker(rank, world, port, n_lap, n_rand, m, out_dir):
+def _worker(rank, world, port, n_lap, n_rand, m, out_dir, overlap=False):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -90,6 +90,8 @@ def _worker(rank, world, port, n_lap, n_rand, m, out_dir):
     ctx = capi.Context(device=rank, rank=rank, world_size=world, rccl_id=ids[0])
     assert ctx.rccl_selftest()
     assert ctx.comm_info()[0] == world
+    if overlap:  # collective: splits off the second communicator; the neighbour exchange then runs beside the interior rows
+        assert ctx.set_halo_overlap(True) is True
     res = _runs(capi, ctx, world, rank, n_lap, n_rand, m)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
     ctx.close()
@@ -97,8 +99,10 @@ def _worker(rank, world, port, n_lap, n_rand, m, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_rccl_ranks_reproduce_the_loopback_run_bit_for_bit(world, tmp_path):
+@pytest.mark.parametrize("world,overlap", [(2, False), (3, False), (2, True)])
+def test_rccl_ranks_reproduce_the_loopback_run_bit_for_bit(world, overlap, tmp_path):
+    """overlap (r3): the neighbour exchange on the second communicator and stream beside the interior rows (opt-in between real
+    ranks) -- the same bits again, by the equivalence the loopback test proves; a hang ends at the join timeout."""
     import multiprocessing as mp
 
     from cmpt_eigenex_amd import capi
@@ -111,11 +115,11 @@ def test_rccl_ranks_reproduce_the_loopback_run_bit_for_bit(world, tmp_path):
     lctx.close()
     port = _free_port()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_lap, n_rand, m, str(tmp_path))) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_lap, n_rand, m, str(tmp_path), overlap)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(timeout=600)
+        p.join(timeout=300 if overlap else 600)
     for p in procs:
         if p.is_alive():
             p.kill()
