@@ -387,19 +387,20 @@ __device__ __forceinline__ double update_tile(const double* src, double* dst,  /
   return nrm;
 }
 
-template <bool CPLX>
+// RED: the second-stage sums of the preceding dots pass are taken here (InlineReduce) -- its own instantiation, so that the
+// common kernel keeps its registers (with both paths in one kernel: 136 VGPRs and three waves per SIMD instead of 128 and four)
+template <bool CPLX, bool RED>
 __global__ __launch_bounds__(kBlock) void k_update(const double* src, double* dst, ThreeTerm tt, ColumnSet cs,
                                                    const double* __restrict__ h, int64_t n, int64_t ntiles,
                                                    double* __restrict__ partials, const Ctrl* __restrict__ ctrl, InlineReduce red) {
-  extern __shared__ double h_lds[];  // red.ncoef coefficients when the second-stage sums of the dots pass are taken here
+  extern __shared__ double h_lds[];  // RED: red.ncoef coefficients
   __shared__ double lds4[4];
   if (ctrl->stopped) return;
   const int ncols = cs.count + cs.nq;
   const double a = tt.uk ? *tt.a : 0.0;
   const double b = (tt.uk && tt.ukm1) ? *tt.b : 0.0;
   const int ntail = tail_columns(tt, cs);
-  double nrm = 0.0;
-  if (red.partials) {  // k_reduce's sums, coefficient by coefficient in its order; workgroup 0 leaves them where k_reduce would have
+  if (RED) {  // k_reduce's sums, coefficient by coefficient in its order; workgroup 0 leaves them where k_reduce would have
     for (int c = 0; c < red.ncoef; ++c) {
       const double* p = red.partials + (int64_t)c * red.pstride;
       double sc = 0.0;
@@ -410,21 +411,15 @@ __global__ __launch_bounds__(kBlock) void k_update(const double* src, double* ds
     __syncthreads();
     if (blockIdx.x == 0)
       for (int c = threadIdx.x; c < red.ncoef; c += kBlock) red.out[c] = h_lds[c];
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-      const int64_t base = tile * kTileRows + 2 * threadIdx.x;
-      if ((tile + 1) * kTileRows <= n)
-        nrm += update_tile<true, CPLX>(src, dst, tt, a, b, cs, ncols, ntail, h_lds, base, n);
-      else
-        nrm += update_tile<false, CPLX>(src, dst, tt, a, b, cs, ncols, ntail, h_lds, base, n);
-    }
-  } else {
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-      const int64_t base = tile * kTileRows + 2 * threadIdx.x;
-      if ((tile + 1) * kTileRows <= n)
-        nrm += update_tile<true, CPLX>(src, dst, tt, a, b, cs, ncols, ntail, h, base, n);
-      else
-        nrm += update_tile<false, CPLX>(src, dst, tt, a, b, cs, ncols, ntail, h, base, n);
-    }
+  }
+  const double* hh = RED ? h_lds : h;
+  double nrm = 0.0;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t base = tile * kTileRows + 2 * threadIdx.x;
+    if ((tile + 1) * kTileRows <= n)
+      nrm += update_tile<true, CPLX>(src, dst, tt, a, b, cs, ncols, ntail, hh, base, n);
+    else
+      nrm += update_tile<false, CPLX>(src, dst, tt, a, b, cs, ncols, ntail, hh, base, n);
   }
   nrm = block_sum(nrm, lds4);
   if (threadIdx.x == 0) partials[blockIdx.x] = nrm;
@@ -1924,10 +1919,14 @@ void launch_update(hipStream_t s, const double* src, double* dst, ThreeTerm tt, 
   const InlineReduce nored{nullptr, 0, 0, 0, nullptr};
   const InlineReduce r = red ? *red : nored;
   const size_t shmem = red ? sizeof(double) * (size_t)red->ncoef : 0;
-  if (cplx)
-    hipLaunchKernelGGL(k_update<true>, dim3(grid), dim3(kBlock), shmem, s, src, dst, tt, cs, h, n, ntiles, partials, ctrl, r);
+  if (red && cplx)
+    hipLaunchKernelGGL((k_update<true, true>), dim3(grid), dim3(kBlock), shmem, s, src, dst, tt, cs, h, n, ntiles, partials, ctrl, r);
+  else if (red)
+    hipLaunchKernelGGL((k_update<false, true>), dim3(grid), dim3(kBlock), shmem, s, src, dst, tt, cs, h, n, ntiles, partials, ctrl, r);
+  else if (cplx)
+    hipLaunchKernelGGL((k_update<true, false>), dim3(grid), dim3(kBlock), 0, s, src, dst, tt, cs, h, n, ntiles, partials, ctrl, r);
   else
-    hipLaunchKernelGGL(k_update<false>, dim3(grid), dim3(kBlock), shmem, s, src, dst, tt, cs, h, n, ntiles, partials, ctrl, r);
+    hipLaunchKernelGGL((k_update<false, false>), dim3(grid), dim3(kBlock), 0, s, src, dst, tt, cs, h, n, ntiles, partials, ctrl, r);
 }
 
 void launch_spmv_z(hipStream_t s, const int32_t* rowptr, const int32_t* col, const double* val, const double* x_ext,

@@ -1293,7 +1293,8 @@ int enq_orthogonalize(eigenex_basis_s* b, int src_ref, int dst_ref, bool three_t
     hipStream_t st = b->ctx->stream;
     BasisShard& s = b->sh[0];
     const int ncoef = (count + nq) * b->es;
-    const bool inline_small = ncoef <= kInlineReduceMaxCoef && std::getenv("EIGENEX_NO_INLINE_FIN") == nullptr;
+    static const bool inline_off = std::getenv("EIGENEX_NO_INLINE_FIN") != nullptr;
+    const bool inline_small = ncoef <= kInlineReduceMaxCoef && !inline_off;
     CHK(enq_dots(b, src_ref, false, 0, first, stride, count, 0, nq, 0, 1));
     CHK(enq_update(b, src_ref, dst_ref, false, 0, first, stride, count, 0, nq, 0, false, 1, 0, -1, -1, /*norm_to_pnorm=*/true));
     if (inline_small) {
