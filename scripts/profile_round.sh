@@ -6,7 +6,7 @@
 #   headline  bench.py 512^3 m=100: kernel trace, FETCH_SIZE, WRITE_SIZE          -> profiles/rNN_summary.md, hbm_traffic.json
 #   config3   scripts/run_config3.py: + L2 (TCC) and L1 (TCP) request counters    -> profiles/rNN_config3_pmc.md
 #   config5   scripts/run_config5.py at N = 2e7: + L2 counters                    -> profiles/rNN_config5_pmc.md
-# and plain (un-profiled) bench lines for the record: headline, 128^3, config 3, config 1, config 3 / 5 script JSONs.
+# and plain (un-profiled) bench lines for the record: headline, 128^3, config 3, config 1, config 5, config 3 / 5 script JSONs.
 set -u
 RND=${1:-r03}
 cd "${GRAFT_REPO_ROOT:-.}"
@@ -21,6 +21,7 @@ run python3 bench.py --steps 5 --warmup 2 > gpurun_out/${RND}_bench.json 2> gpur
 run python3 bench.py --grid-edge 128 --krylov-steps 50 --steps 20 --warmup 5 > gpurun_out/${RND}_bench_128cubed.json 2> gpurun_out/${RND}_bench_128cubed.err
 run python3 bench.py --workload config3 --steps 5 --warmup 2 > gpurun_out/${RND}_bench_config3.json 2> gpurun_out/${RND}_bench_config3.err
 run python3 bench.py --workload config1 --steps 5 --warmup 2 > gpurun_out/${RND}_bench_config1.json 2> gpurun_out/${RND}_bench_config1.err
+run python3 bench.py --workload config5 --steps 2 --warmup 1 > gpurun_out/${RND}_bench_config5.json 2> gpurun_out/${RND}_bench_config5.err
 run python3 scripts/run_config3.py 1000000 80 3 --no-profile --json gpurun_out/${RND}_config3_1gpu.json > gpurun_out/${RND}_config3.log 2>&1
 run python3 scripts/run_config5.py --json gpurun_out/${RND}_config5_1gpu.json > gpurun_out/${RND}_config5.log 2>&1
 tail -c 400 gpurun_out/${RND}_bench.json
