@@ -6,6 +6,8 @@ Tolerances (fp64): SpMV bit-exact (same multiply-then-add order as the oracle);
 dots/norms 1e-13 relative to |x||y| (summation order differs); alpha/beta 1e-12
 absolute; Ritz values 1e-10 relative (north star).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -600,7 +602,7 @@ def test_column_blocked_operator(capi, shards, dtype):
     ctx.close()
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(10 * int(os.environ.get("EIGENEX_FUZZ_SEEDS", "1"))))  # more structures on demand: one long run
 def test_spmv_random_structures_bit_exact(capi, seed):
     """Randomised CSR shapes: tiny and odd row counts, heavy-tailed row lengths (rows longer than several 2048-entry
     LDS chunks next to empty rows), random shard counts and column-block counts -- always bit-identical to the

@@ -7,6 +7,9 @@ the natural scale of each quantity."""
 import numpy as np
 import pytest
 
+# more seeds on demand (one long run instead of repeating the suite): EIGENEX_FUZZ_SEEDS=8 multiplies the number of cases by 8
+_MORE = int(__import__("os").environ.get("EIGENEX_FUZZ_SEEDS", "1"))
+
 pytestmark = pytest.mark.gpu
 
 
@@ -23,7 +26,7 @@ def _rand(rng, shape, cplx):
     return x + 1j * rng.standard_normal(shape) if cplx else x
 
 
-@pytest.mark.parametrize("seed", range(20))
+@pytest.mark.parametrize("seed", range(20 * _MORE))
 def test_primitives_fuzz(capi, seed):
     rng = np.random.default_rng(31000 + seed)
     n = int(rng.choice([1, 3, 63, 64, 65, 255, 257, 2047, 2048, 2049, 4097, 12289]))

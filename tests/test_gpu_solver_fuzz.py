@@ -8,6 +8,9 @@ convergence log's shape and values.  The device runs ahead speculatively and def
 that may show."""
 import numpy as np
 import pytest
+
+# more seeds on demand (one long run instead of repeating the suite): EIGENEX_FUZZ_SEEDS=8 multiplies the number of cases by 8
+_MORE = int(__import__("os").environ.get("EIGENEX_FUZZ_SEEDS", "1"))
 import scipy.sparse as sp
 
 from oracle import krylov_oracle as ko
@@ -30,7 +33,7 @@ def _sym_matrix(rng, n):
     return A
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(24 * _MORE))
 def test_lanczos_front_end_fuzz(mods, seed):
     capi, solver = mods
     rng = np.random.default_rng(7000 + seed)
@@ -122,7 +125,7 @@ def test_lanczos_front_end_fuzz(mods, seed):
     ctx.close()
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(12 * _MORE))
 def test_arnoldi_front_end_fuzz(mods, seed):
     capi, solver = mods
     rng = np.random.default_rng(9000 + seed)
@@ -171,12 +174,15 @@ def test_arnoldi_front_end_fuzz(mods, seed):
     scale = max(1.0, float(np.abs(ref.hessenberg_matrix).max()))
     k = ref.hessenberg_matrix.shape[0]
     np.testing.assert_allclose(r["hessenberg"][:k, :k], ref.hessenberg_matrix, rtol=0, atol=1e-9 * scale)
-    # eigenvalues as multisets (ties in modulus: conjugate pairs may swap)
+    # eigenvalues as multisets (ties in modulus: conjugate pairs may swap; and where maxEigenvalues cuts THROUGH a conjugate pair the
+    # member that is kept is the sort's choice -- std::sort's order of equal keys is unspecified, arnoldi.hpp:813-819 -- so a value
+    # may match the conjugate of the oracle's: seed 102 of the extended run, found by EIGENEX_FUZZ_SEEDS=40)
     got, want = list(r["eigenvalues"]), list(ref.eigenvalues)
     assert len(got) == len(want)
     for x in got:
-        j = int(np.argmin([abs(x - y) for y in want]))
-        assert abs(x - want.pop(j)) <= 1e-7 * scale
+        j = int(np.argmin([min(abs(x - y), abs(x - np.conj(y))) for y in want]))
+        y = want.pop(j)
+        assert min(abs(x - y), abs(x - np.conj(y))) <= 1e-7 * scale
     es.close()
     op.close()
     ctx.close()
