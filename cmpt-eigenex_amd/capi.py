@@ -70,6 +70,7 @@ SIGNATURES = {
     "eigenex_context_trace_get": (C.c_int, [_vp, _ip, _ip, C.c_int, C.POINTER(C.c_int)]),
     "eigenex_plan_create": (C.c_int, [C.c_int64, C.c_int, C.c_int, _ip, _ip, C.POINTER(_vp)]),
     "eigenex_plan_destroy": (C.c_int, [_vp]),
+    "eigenex_plan_tiles": (C.c_int, [_vp, _ip, C.POINTER(C.c_int64), _ip, C.POINTER(C.c_int64)]),
     "eigenex_plan_sizes": (C.c_int, [_vp] + [C.POINTER(C.c_int64)] * 4 + [C.POINTER(C.c_int)] * 2 + [C.POINTER(C.c_int64)]),
     "eigenex_plan_local_columns": (C.c_int, [_vp, _ip]),
     "eigenex_plan_halo_columns": (C.c_int, [_vp, _ip]),
@@ -267,6 +268,14 @@ class ShardPlan:
         out = np.zeros(max(self.sizes()["nnz"], 1), np.int32)
         _chk(lib().eigenex_plan_local_columns(self.h, _i(out)))
         return out[: self.sizes()["nnz"]]
+
+    def tiles(self):
+        """(interior, boundary): the 256-row tiles that read no halo column / at least one (eigenex_plan_tiles)"""
+        ni, nb = C.c_int64(), C.c_int64()
+        _chk(lib().eigenex_plan_tiles(self.h, None, C.byref(ni), None, C.byref(nb)))
+        ti, tb = np.zeros(max(ni.value, 1), np.int32), np.zeros(max(nb.value, 1), np.int32)
+        _chk(lib().eigenex_plan_tiles(self.h, _i(ti), C.byref(ni), _i(tb), C.byref(nb)))
+        return ti[:ni.value], tb[:nb.value]
 
     def halo_columns(self):
         out = np.zeros(max(self.sizes()["n_halo"], 1), np.int32)

@@ -477,6 +477,19 @@ int operator_partials(const CsrShard* m, int64_t nloc, int blocks_per_cu, int* f
   return grid_for_tiles((nloc + kSpmvRows - 1) / kSpmvRows, blocks_per_cu);
 }
 
+// which 256-row tiles of a shard read a halo column (local numbering: >= npad)?  lrp: rebased row pointers (int32 or int64)
+template <class RP>
+std::vector<uint8_t> boundary_tile_flags(int64_t nloc, int64_t npad, const RP& lrp, const std::vector<int32_t>& lcol) {
+  std::vector<uint8_t> bnd((size_t)((nloc + kSpmvRows - 1) / kSpmvRows), 0);
+  for (int64_t r = 0; r < nloc; ++r)
+    for (int64_t p = lrp[(size_t)r]; p < lrp[(size_t)r + 1]; ++p)
+      if (lcol[(size_t)p] >= npad) {
+        bnd[(size_t)(r / kSpmvRows)] = 1;
+        break;
+      }
+  return bnd;
+}
+
 // interior / boundary tile lists of a plain CSR shard from a per-tile flag (host), uploaded
 int upload_tile_lists(eigenex_context_s* c, CsrShard& s, const std::vector<uint8_t>& is_boundary) {
   std::vector<int32_t> ti, tb;
@@ -761,16 +774,7 @@ int build_shard_host_wide(eigenex_context_s* c, int64_t n_global, int gshard, co
   CHK(plan_shard_entries(n_global, c->P, gshard, rowptr[nloc] - p0, col + p0, 1, s, lcol));
   std::vector<int64_t> lrp((size_t)nloc + 1);
   for (int64_t i = 0; i <= nloc; ++i) lrp[(size_t)i] = rowptr[i] - p0;
-  if (c->P > 1 && nloc > 0) {
-    std::vector<uint8_t> bnd((size_t)((nloc + kSpmvRows - 1) / kSpmvRows), 0);
-    for (int64_t r = 0; r < nloc; ++r)
-      for (int64_t p = lrp[(size_t)r]; p < lrp[(size_t)r + 1]; ++p)
-        if (lcol[(size_t)p] >= s.npad) {
-          bnd[(size_t)(r / kSpmvRows)] = 1;
-          break;
-        }
-    CHK(upload_tile_lists(c, s, bnd));
-  }
+  if (c->P > 1 && nloc > 0) CHK(upload_tile_lists(c, s, boundary_tile_flags(nloc, s.npad, lrp, lcol)));
   HIPCHK(hipMalloc(&s.rowptr64, sizeof(int64_t) * (size_t)(nloc + 1)));
   HIPCHK(hipMalloc(&s.col, sizeof(int32_t) * (size_t)(s.nnz + kCsrTailPad)));
   HIPCHK(hipMalloc(&s.val, sizeof(double) * (size_t)(s.nnz + kCsrTailPad)));
@@ -871,16 +875,7 @@ int build_shard_host(eigenex_context_s* c, int64_t n_global, int gshard, const i
     lcol.swap(bcol);
     vsrc = bval.data();
   }
-  if (s.passes == 1 && es == 1 && c->P > 1 && s.nloc > 0) {  // which tiles read a halo column (local numbering: >= npad)
-    std::vector<uint8_t> bnd((size_t)((s.nloc + kSpmvRows - 1) / kSpmvRows), 0);
-    for (int64_t r = 0; r < s.nloc; ++r)
-      for (int64_t p = lrp[(size_t)r]; p < lrp[(size_t)r + 1]; ++p)
-        if (lcol[(size_t)p] >= s.npad) {
-          bnd[(size_t)(r / kSpmvRows)] = 1;
-          break;
-        }
-    CHK(upload_tile_lists(c, s, bnd));
-  }
+  if (s.passes == 1 && es == 1 && c->P > 1 && s.nloc > 0) CHK(upload_tile_lists(c, s, boundary_tile_flags(s.nloc, s.npad, lrp, lcol)));
   const size_t nrp = (size_t)s.passes * (s.nloc + 1);
   HIPCHK(hipMalloc(&s.rowptr, sizeof(int32_t) * nrp));
   HIPCHK(hipMalloc(&s.col, sizeof(int32_t) * (s.nnz + kCsrTailPad)));
@@ -1935,7 +1930,7 @@ struct eigenex_plan_s {
   int64_t n_global = 0;
   int P = 1;
   CsrShard s;
-  std::vector<int32_t> lcol, send_rows;
+  std::vector<int32_t> lcol, send_rows, lrp;  // lrp: the shard's row pointers rebased to 0
 };
 extern "C" {
 
@@ -1955,7 +1950,27 @@ int eigenex_plan_create(int64_t n_global, int nshards, int shard, const int32_t*
     delete p;
     return rc;
   }
+  p->lrp.resize((size_t)(re - rb) + 1);
+  for (int64_t i = 0; i <= re - rb; ++i) p->lrp[(size_t)i] = rowptr[i] - rowptr[0];
   *out = p;
+  return 0;
+}
+
+int eigenex_plan_tiles(eigenex_plan_t p, int32_t* interior, int64_t* n_interior, int32_t* boundary, int64_t* n_boundary) {
+  if (!p) return fail(EIGENEX_ERR_ARG, "plan is NULL");
+  const std::vector<uint8_t> bnd = boundary_tile_flags(p->s.nloc, p->s.npad, p->lrp, p->lcol);  // the code the upload runs
+  int64_t ni = 0, nb = 0;
+  for (size_t t = 0; t < bnd.size(); ++t) {
+    if (bnd[t]) {
+      if (boundary) boundary[nb] = (int32_t)t;
+      ++nb;
+    } else {
+      if (interior) interior[ni] = (int32_t)t;
+      ++ni;
+    }
+  }
+  if (n_interior) *n_interior = ni;
+  if (n_boundary) *n_boundary = nb;
   return 0;
 }
 

@@ -121,6 +121,10 @@ int eigenex_plan_sizes(eigenex_plan_t plan, int64_t* n_local, int64_t* n_pad, in
                        int* n_send, int64_t* n_send_rows);
 /* local column of every stored entry: [0, n_local) own rows, n_pad + s = halo slot s */
 int eigenex_plan_local_columns(eigenex_plan_t plan, int32_t* lcol);
+/* r3: the shard's 256-row tiles that read no halo column (interior) and those that read at least one (boundary), ascending --
+ * the two launches of a plain CSR operator between shards: the interior tiles need nothing from the neighbour exchange and may
+ * run beside it (eigenex_context_set_halo_overlap).  Either array may be NULL (counts only). */
+int eigenex_plan_tiles(eigenex_plan_t plan, int32_t* interior, int64_t* n_interior, int32_t* boundary, int64_t* n_boundary);
 /* global column of every halo slot (ascending: grouped by owner) */
 int eigenex_plan_halo_columns(eigenex_plan_t plan, int32_t* cols_global);
 /* receive segment i: halo slots [offset[i], offset[i]+count[i]) come from shard peer[i]; the request to that owner is

@@ -35,6 +35,14 @@ int main(void) {
   CHECK(lcol[0] == 64 && lcol[1] == 0 && lcol[2] == 1 && lcol[8] == 65); /* halo slots sit behind the padded rows */
   CHECK(eigenex_plan_recv_segments(plan, peer, off, cnt) == 0);
   CHECK(peer[0] == 0 && off[0] == 0 && cnt[0] == 1 && peer[1] == 2 && off[1] == 1 && cnt[1] == 1);
+  {
+    /* three rows = one 256-row tile, and it reads halo columns: no interior tile, one boundary tile */
+    int32_t ti[1], tb[1];
+    int64_t ni = -1, nb = -1;
+    CHECK(eigenex_plan_tiles(plan, NULL, &ni, NULL, &nb) == 0 && ni == 0 && nb == 1);
+    CHECK(eigenex_plan_tiles(plan, ti, &ni, tb, &nb) == 0 && tb[0] == 0);
+    CHECK(eigenex_plan_tiles(NULL, ti, &ni, tb, &nb) < 0);
+  }
   /* the neighbours ask for row 3 (shard 0) and row 5 (shard 2) */
   {
     const int32_t want0[1] = {3}, want2[1] = {5};

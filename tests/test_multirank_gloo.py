@@ -50,7 +50,7 @@ def _matrix(kind, n):
     return N, A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
 
 
-def _worker(rank, world, port, kind, n, m, fusion, out_dir):
+def _worker(rank, world, port, kind, n, m, fusion, out_dir, overlap=False):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -93,7 +93,7 @@ def _worker(rank, world, port, kind, n, m, fusion, out_dir):
     if kind == "laplacian":
         assert all(s[3] >= 0 for s in send)
 
-    def halo_exchange(x_ext):
+    def halo_post(x_ext):
         reqs, bufs = [], {}
         for peer, off, cnt, contig in send:
             rows = send_rows[off:off + cnt]
@@ -101,10 +101,30 @@ def _worker(rank, world, port, kind, n, m, fusion, out_dir):
         for o, off, cnt in recv:
             bufs[(o, off, cnt)] = torch.empty(cnt, dtype=torch.float64)
             reqs.append(dist.irecv(bufs[(o, off, cnt)], o))
+        return reqs, bufs
+
+    def halo_wait(x_ext, posted):
+        reqs, bufs = posted
         for q in reqs:
             q.wait()
         for (o, off, cnt), t in bufs.items():
             x_ext[npad + off: npad + off + cnt] = t.numpy()
+
+    def halo_exchange(x_ext):
+        halo_wait(x_ext, halo_post(x_ext))
+
+    # r3 -- the exchange beside the interior rows (eigenex_context_set_halo_overlap): the library's own tile lists say which
+    # 256-row tiles need nothing from the neighbours.  The operator is applied to those while the messages are in flight and
+    # the halo region still holds NaN; the boundary tiles follow the wait.  Must equal the exchange-first product bit for bit.
+    tiles_int, tiles_bnd = plan.tiles()
+    assert np.array_equal(np.sort(np.concatenate([tiles_int, tiles_bnd])), np.arange((nloc + 255) // 256))
+    row_tile = np.arange(nloc) // 256
+    reads_halo = np.zeros(nloc, bool)
+    np.logical_or.at(reads_halo, np.repeat(np.arange(nloc), np.diff(rowptr)), lcol >= npad)
+    assert not reads_halo[np.isin(row_tile, tiles_int)].any()                      # interior tiles read no halo column
+    assert all(reads_halo[row_tile == t].any() for t in tiles_bnd)                  # every boundary tile reads one
+    if world > 1 and kind == "laplacian":
+        assert tiles_bnd.size > 0
 
     # ---- schedule: the library says which collective comes next; the arithmetic must agree ----
     class Schedule:
@@ -126,15 +146,40 @@ def _worker(rank, world, port, kind, n, m, fusion, out_dir):
         def halo(self, x_ext):
             op, _ = self.queue.pop(0)
             assert op == capi.COLL_HALO
-            halo_exchange(x_ext)
+            if not overlap:
+                halo_exchange(x_ext)
+                return None
+            x_ext[npad:] = np.nan  # what the interior rows must not touch
+            return halo_post(x_ext)
 
         def end_call(self):
             assert not self.queue, self.queue
 
-    def spmv(x_ext):  # the shard's rows: products in stored order
-        prod = val * x_ext[lcol]
+    entry_row = np.repeat(np.arange(nloc), np.diff(rowptr))
+
+    def spmv_rows(x_ext, y, tiles):  # the rows of the given tiles: products in stored order
+        sel = np.isin(entry_row // 256, tiles)
+        np.add.at(y, entry_row[sel], val[sel] * x_ext[lcol[sel]])
+
+    def spmv(x_ext, posted=None):
         y = np.zeros(nloc)
-        np.add.at(y, np.repeat(np.arange(nloc), np.diff(rowptr)), prod)
+        if posted is None:  # exchange first: one pass over all rows, as before
+            np.add.at(y, entry_row, val * x_ext[lcol])
+            return y
+        spmv_rows(x_ext, y, tiles_int)       # while the messages travel
+        assert np.isfinite(y).all()          # no interior row has read the poisoned halo region
+        halo_wait(x_ext, posted)
+        spmv_rows(x_ext, y, tiles_bnd)
+        return y
+
+    def spmv_scaled(x_ext, scale, posted):  # the operator scales its input on the fly (scale: the same function of an array
+        y = np.zeros(nloc)                   # as in the exchange-first run); the halo arrives unscaled
+        sel = np.isin(entry_row // 256, tiles_int)
+        np.add.at(y, entry_row[sel], val[sel] * scale(x_ext[lcol[sel]]))
+        assert np.isfinite(y).all()
+        halo_wait(x_ext, posted)
+        sel = np.isin(entry_row // 256, tiles_bnd)
+        np.add.at(y, entry_row[sel], val[sel] * scale(x_ext[lcol[sel]]))
         return y
 
     sch = Schedule()
@@ -152,9 +197,9 @@ def _worker(rank, world, port, kind, n, m, fusion, out_dir):
     sch.begin_call(last_flags[0])
     w[:nloc] = init
     nrm = np.sqrt(sch.allreduce(w[:nloc] @ w[:nloc])[0])
-    sch.halo(w)
+    posted = sch.halo(w)
     V[0] = w[:nloc] / nrm
-    v = spmv(w / nrm)
+    v = spmv(w / nrm, None) if posted is None else spmv_scaled(w, lambda a: a / nrm, posted)
     if sch.pending:
         a_local = V[0] @ v
     else:
@@ -180,9 +225,9 @@ def _worker(rank, world, port, kind, n, m, fusion, out_dir):
         b = np.sqrt(sch.allreduce(wk @ wk)[0])
         beta.append(b)
         w[:nloc] = wk
-        sch.halo(w)
+        posted = sch.halo(w)
         V[k + 1] = wk * (1.0 / b)
-        v = spmv(w * (1.0 / b))
+        v = spmv(w * (1.0 / b), None) if posted is None else spmv_scaled(w, lambda a: a * (1.0 / b), posted)
         if sch.pending:
             a_local = V[k + 1] @ v
         else:
@@ -208,23 +253,32 @@ def test_sharded_lanczos_matches_single_process_oracle(world, kind, n, fusion, t
     m = 25
     N, rowptr, col, val = _matrix(kind, n)
     assert kind == "laplacian" or N % world != 0 or world == 2  # (3, 1000): uneven partition
-    port = _free_port()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, n, m, fusion, str(tmp_path))) for r in range(world)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(timeout=300)
-    for p in procs:
-        if p.is_alive():
-            p.kill()
-        assert p.exitcode == 0
     init = np.random.default_rng(7).standard_normal(N)
     ref = cref.CLanczos(rowptr, col, val, init, cap=m + 2)
     assert ref.run(m + 1) == m + 1
     want = np.concatenate([ref.alpha, ref.beta])
-    for r in range(world):
-        got = np.load(tmp_path / f"ab_{r}.npy")
-        np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
-        if r:
-            np.testing.assert_array_equal(got, np.load(tmp_path / "ab_0.npy"))  # ranks agree bit for bit
+    results = {}
+    # r3: with the alpha fusion on, the run is repeated with the neighbour exchange posted asynchronously and the interior tiles
+    # (the library's own lists, eigenex_plan_tiles) multiplied while it is in flight: the same bits
+    for overlap in ([False, True] if fusion else [False]):
+        out_dir = tmp_path / f"overlap{int(overlap)}"
+        out_dir.mkdir()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, kind, n, m, fusion, str(out_dir), overlap)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=300)
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+            assert p.exitcode == 0
+        for r in range(world):
+            got = np.load(out_dir / f"ab_{r}.npy")
+            np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
+            if r:
+                np.testing.assert_array_equal(got, np.load(out_dir / "ab_0.npy"))  # ranks agree bit for bit
+        results[overlap] = np.load(out_dir / "ab_0.npy")
+    if True in results:
+        np.testing.assert_array_equal(results[True], results[False])
