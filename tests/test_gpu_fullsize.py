@@ -446,3 +446,48 @@ print(' '.join(x.hex() for x in list(al) + list(be)))
         out[probe] = (r.stdout.strip().splitlines()[-1], r.stderr.count("placement candidate"))
     assert out[True][0] == out[False][0] and len(out[True][0].split()) == 13
     assert out[True][1] >= 2 and out[False][1] == 0
+
+
+@pytest.mark.skipif(not os.environ.get("EIGENEX_BIG_TESTS"), reason="opt-in (EIGENEX_BIG_TESTS=1): 60 GB of host arrays, minutes")
+def test_upload64_more_than_2_31_entries(capi):
+    """eigenex_csr_upload64 at the size it exists for: 7e7 rows x 32 entries = 2.24e9 stored entries (> 2^31) handed over as
+    host CSR with 64-bit row pointers, stored as ONE shard with 64-bit row pointers on the device.  The matrix is a sum of 32
+    cyclic shifts with weights (row r holds w_k at column (r + s_k) mod N, stored in ascending column order), so that
+    y = sum_k w_k roll(x, -s_k) is known without a CSR loop on the host (the oracle's row loop takes 32-bit row pointers); weights
+    and input are small integers, so every order of summation gives the same bits and the comparison is exact.  Run once in
+    round 3; opt-in because of its size."""
+    N, per = 70_000_000, 32
+    rng = np.random.default_rng(64)
+    shifts = np.sort(rng.choice(np.arange(1, N), per, replace=False)).astype(np.int64)
+    w = rng.integers(-4, 5, per).astype(np.float64)  # integer weights and integer x: every summation order is exact
+    rowptr = np.arange(N + 1, dtype=np.int64) * per
+    assert rowptr[-1] > 2 ** 31
+    col = np.empty(N * per, np.int32)
+    val = np.empty(N * per, np.float64)
+    blk = 2_000_000
+    for r0 in range(0, N, blk):
+        r1 = min(N, r0 + blk)
+        c = (np.arange(r0, r1, dtype=np.int64)[:, None] + shifts[None, :]) % N
+        order = np.argsort(c, axis=1, kind="stable")
+        col[r0 * per:r1 * per] = np.take_along_axis(c, order, axis=1).astype(np.int32).ravel()
+        val[r0 * per:r1 * per] = w[order].ravel()
+    x = rng.integers(-3, 4, N).astype(np.float64)
+    y_ref = np.zeros(N)
+    for k in range(per):
+        y_ref += w[k] * np.roll(x, -int(shifts[k]))
+    ctx = capi.Context()
+    try:
+        A = capi.Csr.upload64(ctx, N, rowptr, col, val)
+        b = capi.Basis(ctx, A, N, 2)
+    except capi.EigenexError as e:  # pragma: no cover
+        pytest.skip(f"not enough memory: {e}")
+    assert A.info()["nnz_local"] == N * per and A.layout() == "csr"
+    del col, val
+    b.upload(capi.VEC_W, x)
+    dot = b.apply(capi.VEC_W, capi.VEC_V, 0.0, want_dot=True)
+    y = b.download(capi.VEC_V)
+    np.testing.assert_array_equal(y, y_ref)
+    assert dot == float(x @ y_ref)
+    b.close()
+    A.close()
+    ctx.close()
