@@ -105,7 +105,15 @@ def test_lanczos_front_end_fuzz(mods, seed):
                 res_ref = np.abs(A @ ref.eigenvectors - ref.eigenvectors * ref.eigenvalues).max()
                 assert res <= 10 * res_ref + 1e-9 * scale, tag  # as good as the oracle's (unconverged pairs are not small)
         else:
-            assert abs(r["iterations"] - ref.base.iterations) <= 2, tag
+            # (how far apart grows with the length of the run: 65 against 68 iterations at seed 1331 of an extended run,
+            # EIGENEX_FUZZ_SEEDS=200.  Long tolerance-driven runs with strided re-orthogonalisation have BIMODAL exits: ghost copies
+            # of converged Ritz values shift the watched indices, and when that happens depends on rounding.  Seeds 2374 / 3797 of
+            # that run: oracle 73 / 61 iterations, device on two shards 55 / 84 -- and the ORACLE ITSELF exits at 55 / 84-85 in 2 of 21
+            # runs each when its start vector is perturbed by 1e-13 .. 1e-9 relative (tests/probes/fuzz_interval_case.py; one and
+            # three shards land on the oracle's mode, alpha agrees to 1e-15 for the first 40 steps in every variant).  So: two
+            # steps or 5 % for short runs, 40 % for long ones; what must agree is how the run ends, below.)
+            its = ref.base.iterations
+            assert abs(r["iterations"] - its) <= (max(2, its // 20) if its < 40 else max(3, (2 * its) // 5)), tag
             assert es.log()[0] == ref.log[0] and es.log()[-1] == ref.log[-1], tag
         # info() (not in the reference) is derived from the events of the LATEST run, i.e. the log lines after the last
         # "... was called" marker (compute() erases its own marker together with the old log, lanczos.hpp:719-721)
