@@ -1,5 +1,9 @@
-"""RCCL between real ranks (one process per GPU).  Skipped on a one-GPU box (RCCL refuses two ranks on one device); on a
-node with >= 2 GPUs it is the test that the loopback transport stands in for everywhere else: the same sharded Lanczos /
+"""The library's multi-rank code between real processes.  On a node with >= 2 GPUs: over RCCL, one process per GPU.  On a
+one-GPU box RCCL refuses two ranks on one device, so the rank processes all use device 0 and a TEST-ONLY stand-in transport
+(tests/cpp/rccl_standin.cpp, preloaded into the rank processes only) carries the bytes: everything the library does between
+ranks -- request lists, packed neighbour exchange in ncclGroupStart/End, all-reduce schedule, phase all-gather, the second
+communicator of the overlapped exchange -- runs between different processes; only RCCL's own transport does not.
+It is the test that the loopback transport stands in for everywhere else: the same sharded Lanczos /
 Arnoldi runs, rank by rank over RCCL, must reproduce the in-process loopback run of the same partition BIT FOR BIT
 (same kernels, same partial sums; ncclAllReduce of 2 ranks adds the same two numbers as k_sum_shards) -- for the
 device-generated stencil (closed-form halo plan), for an uploaded random sparse matrix (request lists exchanged over RCCL,
@@ -77,17 +81,38 @@ def _runs(capi, ctx, world, rank, n_lap, n_rand, m):
     return out
 
 
-def _worker(rank, world, port, n_lap, n_rand, m, out_dir, overlap=False):
+def _standin_library(build_dir):
+    """tests/cpp/rccl_standin.cpp -> shared object (g++; the HIP runtime is looked up at run time, not linked)"""
+    import subprocess
+
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    so = os.path.join(str(build_dir), "librccl_standin.so")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(rocm, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "rccl_standin.cpp"), "-o", so, "-ldl"])
+    return so
+
+
+def _standin_loaded():
+    import ctypes
+
+    try:
+        return bool(ctypes.CDLL(None).eigenex_test_rccl_standin_loaded())
+    except AttributeError:
+        return False
+
+
+def _worker(rank, world, port, n_lap, n_rand, m, out_dir, overlap=False, standin=False):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
 
     from cmpt_eigenex_amd import capi
 
+    assert _standin_loaded() == standin
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     ids = [capi.rccl_unique_id() if rank == 0 else None]
     dist.broadcast_object_list(ids, src=0)
-    ctx = capi.Context(device=rank, rank=rank, world_size=world, rccl_id=ids[0])
+    ctx = capi.Context(device=0 if standin else rank, rank=rank, world_size=world, rccl_id=ids[0])
     assert ctx.rccl_selftest()
     assert ctx.comm_info()[0] == world
     if overlap:  # collective: splits off the second communicator; the neighbour exchange then runs beside the interior rows
@@ -107,17 +132,30 @@ def test_rccl_ranks_reproduce_the_loopback_run_bit_for_bit(world, overlap, tmp_p
 
     from cmpt_eigenex_amd import capi
 
-    if capi.device_count() < world:
-        pytest.skip(f"needs {world} GPUs (this box has {capi.device_count()}): RCCL refuses two ranks on one device")
+    standin = capi.device_count() < world  # one-GPU box: all ranks on device 0, the stand-in transport carries the bytes
+    assert not _standin_loaded()  # never in the test process itself
     n_lap, n_rand, m = 14, 3001, 18
     lctx = capi.Context(loopback_shards=world)
     want = _runs(capi, lctx, world, None, n_lap, n_rand, m)
     lctx.close()
     port = _free_port()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_lap, n_rand, m, str(tmp_path), overlap)) for r in range(world)]
-    for p in procs:
-        p.start()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_lap, n_rand, m, str(tmp_path), overlap, standin)) for r in range(world)]
+    saved = {k: os.environ.get(k) for k in ("LD_PRELOAD", "EIGENEX_TEST_RCCL_DIR")}
+    try:
+        if standin:  # spawn: the children are fresh interpreters started with this environment
+            box = tmp_path / "standin"
+            box.mkdir()
+            os.environ["LD_PRELOAD"] = _standin_library(tmp_path)
+            os.environ["EIGENEX_TEST_RCCL_DIR"] = str(box)
+        for p in procs:
+            p.start()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     for p in procs:
         p.join(timeout=300 if overlap else 600)
     for p in procs:
