@@ -97,7 +97,7 @@ def launch_ranks(nranks: int, argv) -> int:
     have = visible_gpus_without_touching_them()
     if "--launch-check" in argv:
         have = None
-    if have is not None and have < nranks:
+    if have is not None and have < nranks and not os.environ.get("BENCH_REHEARSAL"):
         print(f"bench.py: --gpus {nranks} needs {nranks} GPUs, this machine shows {have}", file=sys.stderr)
         return 2
     with socket.socket() as s:
@@ -445,9 +445,13 @@ def main():
     ndev = capi.device_count()
     narrowed = (any(os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
                 and not os.environ.get("BENCH_SELF_LAUNCHED"))  # our own ranks all inherit one and the same device list
+    # BENCH_REHEARSAL=1 (tests only): every rank on device 0, the torch process group over gloo with host tensors -- what a
+    # one-GPU box can rehearse of the N > 1 run when a test preloads a stand-in transport for the library's RCCL calls
+    # (tests/test_gpu_rccl_ranks.py).  The line then carries "rehearsal" and is not a measurement.
+    rehearsal = bool(os.environ.get("BENCH_REHEARSAL"))
     if local_rank < ndev:
         dev_index = local_rank
-    elif narrowed and ndev == 1:
+    elif (narrowed or rehearsal) and ndev == 1:
         dev_index = 0
     else:
         sys.exit(f"rank {rank}: needs GPU index {local_rank} but this process sees {ndev} device(s): "
@@ -465,8 +469,12 @@ def main():
             with socket.socket() as sk:
                 sk.bind(("127.0.0.1", 0))
                 os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
-        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+        pg_dev = torch.device("cpu") if rehearsal else dev
+        if rehearsal:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        idt = torch.zeros(128, dtype=torch.uint8, device=pg_dev)
         if rank == 0:
             idt.copy_(torch.frombuffer(bytearray(capi.rccl_unique_id()), dtype=torch.uint8))
         dist.broadcast(idt, src=0)
@@ -534,7 +542,7 @@ def main():
 
     multi = None
     if multi_path:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=pg_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
         # per-rank view: what the communicator itself says, kernel and collective times, halo volume
@@ -542,7 +550,7 @@ def main():
         info = A.info()
         mine = torch.tensor([ranks, crank, cdev, info["n_local"], info["n_halo_local"]] +
                             [prof[k][1] for k in ("spmv", "dots", "update", "small", "comm")] +
-                            [prof["update"][0], prof["comm"][0]], dtype=torch.float64, device=dev)
+                            [prof["update"][0], prof["comm"][0]], dtype=torch.float64, device=pg_dev)
         allv = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allv, mine)
         tab = np.array([v.cpu().numpy() for v in allv])
@@ -644,6 +652,8 @@ def main():
                                                 "note": "the same steps repeated with the per-launch HIP events off (rank-0 clock)"}
         if multi is not None:
             out["multi_gpu"] = multi
+        if rehearsal:
+            out["rehearsal"] = "BENCH_REHEARSAL=1: ranks share device 0, gloo process group: NOT a measurement"
         if world == 1 and not args.no_cpu_baseline:
             cb, same_input = cpu_baseline(n, m, init, N, nnz_global, m)
             if same_input is not None:

@@ -187,3 +187,37 @@ def test_one_rank_communicator_runs_the_same_cases():
     ctx.close()
     for key, v in want.items():
         np.testing.assert_allclose(got[key], v, rtol=0, atol=1e-11, err_msg=key)
+
+
+@pytest.mark.parametrize("world,flags", [(2, []), (4, ["--halo-overlap"])])
+def test_bench_line_of_a_multi_rank_run_rehearsed_on_one_gpu(world, flags, tmp_path):
+    """bench.py --gpus N end to end with N real rank processes on a box with fewer GPUs: its own launcher, the process group,
+    the id broadcast, the sharded stencil with its neighbour exchange, max-over-ranks timing and the multi_gpu block -- with
+    BENCH_REHEARSAL=1 (ranks share device 0, gloo process group) and the stand-in transport preloaded.  What is checked is
+    that the run completes and that the line describes N ranks with the right shards; its rate is not a measurement."""
+    import json
+    import subprocess
+
+    from cmpt_eigenex_amd import capi
+
+    if capi.device_count() >= world:
+        pytest.skip("this node has the GPUs for the real run: bench.py --gpus N over RCCL is the driver's job there")
+    box = tmp_path / "standin"
+    box.mkdir()
+    env = dict(os.environ, LD_PRELOAD=_standin_library(tmp_path), EIGENEX_TEST_RCCL_DIR=str(box), BENCH_REHEARSAL="1")
+    n, m = 40, 12
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--n", str(n), "--m", str(m), "--steps", "2",
+                          "--warmup", "1", *flags], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-4000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines  # exactly one line on stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == world and "rehearsal" in line and line["value"] > 0
+    mg = line["multi_gpu"]
+    assert mg["rccl_ranks"] == world and mg["rccl_rank_of_each_process"] == list(range(world))
+    assert sum(mg["rows_per_rank"]) == n ** 3
+    assert mg["rows_per_rank"] == [capi.partition(n ** 3, world, r)[1] - capi.partition(n ** 3, world, r)[0] for r in range(world)]
+    plane = n * n
+    want_halo = [plane * ((r > 0) + (r < world - 1)) * 8 for r in range(world)]  # 1-D row shards of a 7-point stencil: a plane per side
+    assert mg["halo_bytes_per_step_per_rank"] == want_halo
+    assert mg["halo_overlap"] == bool(flags)
