@@ -68,6 +68,34 @@ def _runs(capi, ctx, world, rank, n_lap, n_rand, m):
         out[f"{name}_arnoldi"] = b.arnoldi_state()[1].ravel()
         b.close()
         A.close()
+    # the solver classes over the same ranks (header-only C++ through the solver bindings): eigenvalues on every rank, Ritz
+    # vectors as the rank's rows ("rows:" keys are compared with the rank's slice of the loopback result)
+    from cmpt_eigenex_amd import solver
+
+    rowptr, col, val = rnd
+    N = n_rand
+    sl = slice(None) if rank is None else slice(*capi.partition(N, world, rank))
+    if rank is None:
+        A = capi.Csr.upload(ctx, N, rowptr, col, val)
+    else:
+        rb, re = sl.start, sl.stop
+        A = capi.Csr.upload(ctx, N, rowptr[rb:re + 1] - rowptr[rb], col[rowptr[rb]:rowptr[re]], val[rowptr[rb]:rowptr[re]], row_begin=rb)
+    init = np.random.default_rng(11).standard_normal(N)
+    es = solver.LanczosEigenSolver()
+    es.setDeviceOperator(A).set(minIterations=2 * m, maxIterations=2 * m, maxEigenvalues=3, initialVector=init)
+    es.compute()
+    r = es.results()
+    out["solver_lanczos_values"] = np.asarray(r["eigenvalues"])
+    out["rows:solver_lanczos_vectors"] = np.asarray(r["eigenvectors"])
+    es.close()
+    tr = solver.ThickRestartLanczosEigenSolver()
+    tr.setDeviceOperator(A).set(numberOfEigenvalues=2, maxBasisSize=24, tolerance=1e-9, maxRestarts=40, initialVector=init)
+    tr.compute()
+    r = tr.results()
+    out["solver_thick_restart_values"] = np.concatenate([np.asarray(r["eigenvalues"]), np.asarray(r["residuals"]), [r["restarts"]]])
+    out["rows:solver_thick_restart_vectors"] = np.asarray(r["eigenvectors"])
+    tr.close()
+    A.close()
     A = capi.Csr.laplacian3d(ctx, n_lap)
     N = n_lap ** 3
     sl = slice(None) if rank is None else slice(*capi.partition(N, world, rank))
@@ -128,8 +156,6 @@ def _worker(rank, world, port, n_lap, n_rand, m, out_dir, overlap=False, standin
 def test_rccl_ranks_reproduce_the_loopback_run_bit_for_bit(world, overlap, tmp_path):
     """overlap (r3): the neighbour exchange on the second communicator and stream beside the interior rows (opt-in between real
     ranks) -- the same bits again, by the equivalence the loopback test proves; a hang ends at the join timeout."""
-    import multiprocessing as mp
-
     from cmpt_eigenex_amd import capi
 
     standin = capi.device_count() < world  # one-GPU box: all ranks on device 0, the stand-in transport carries the bytes
@@ -139,37 +165,18 @@ def test_rccl_ranks_reproduce_the_loopback_run_bit_for_bit(world, overlap, tmp_p
     want = _runs(capi, lctx, world, None, n_lap, n_rand, m)
     lctx.close()
     port = _free_port()
-    ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_lap, n_rand, m, str(tmp_path), overlap, standin)) for r in range(world)]
-    saved = {k: os.environ.get(k) for k in ("LD_PRELOAD", "EIGENEX_TEST_RCCL_DIR")}
-    try:
-        if standin:  # spawn: the children are fresh interpreters started with this environment
-            box = tmp_path / "standin"
-            box.mkdir()
-            os.environ["LD_PRELOAD"] = _standin_library(tmp_path)
-            os.environ["EIGENEX_TEST_RCCL_DIR"] = str(box)
-        for p in procs:
-            p.start()
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-    for p in procs:
-        p.join(timeout=300 if overlap else 600)
-    for p in procs:
-        if p.is_alive():
-            p.kill()
-        assert p.exitcode == 0
+    _start_ranks(_worker, lambda r: (r, world, port, n_lap, n_rand, m, str(tmp_path), overlap, standin), world, standin, tmp_path,
+                 300 if overlap else 600)
     for r in range(world):
         got = np.load(tmp_path / f"rank{r}.npz")
         for key, v in want.items():
+            if key.startswith("rows:"):  # a rank holds its own rows of what the loopback context returns whole
+                v = v[slice(*capi.partition(v.shape[0], world, r))]
             if world == 2:  # a + b is the same number in either order
                 np.testing.assert_array_equal(got[key], v, err_msg=f"rank {r} {key}")
             else:  # three addends: RCCL's reduction order is its own
-                np.testing.assert_allclose(got[key], v, rtol=0, atol=1e-11, err_msg=f"rank {r} {key}")
-            if r:
+                np.testing.assert_allclose(got[key], v, rtol=0, atol=1e-9 if "solver" in key else 1e-11, err_msg=f"rank {r} {key}")
+            if r and not key.startswith("rows:"):
                 np.testing.assert_array_equal(got[key], np.load(tmp_path / "rank0.npz")[key])  # ranks agree bit for bit
 
 
@@ -187,6 +194,136 @@ def test_one_rank_communicator_runs_the_same_cases():
     ctx.close()
     for key, v in want.items():
         np.testing.assert_allclose(got[key], v, rtol=0, atol=1e-11, err_msg=key)
+
+
+def _scattered(rng, n, per):
+    """n x n, `per` uniformly placed entries per row (scipy.sparse.random samples without replacement from n^2 cells: minutes here)"""
+    import scipy.sparse as sp
+
+    return sp.coo_matrix((rng.standard_normal(n * per), (np.repeat(np.arange(n), per), rng.integers(0, n, n * per))), shape=(n, n)).tocsr()
+
+
+def _format_runs(capi, ctx, world, rank, m):
+    """the operator formats and the complex scalar type of the library over `world` ranks: alpha/beta of m Lanczos steps each"""
+    sys.path.insert(0, ROOT)
+    import scipy.sparse as sp
+
+    from cmpt_eigenex_amd import synthetic
+
+    out = {}
+
+    def lanczos(A, N, init, key):
+        sl = slice(None) if rank is None else slice(*capi.partition(N, world, rank))
+        b = capi.Basis(ctx, A, N, m + 1)
+        b.upload(capi.VEC_W, init[sl])
+        b.lanczos_enqueue(m + 1)
+        st, al, be = b.lanczos_state()
+        assert st.nvec == m + 1 and st.stopped == 0
+        out[key] = np.concatenate([al, be])
+        out["rows:" + key + "_last_vector"] = b.download(capi.VEC_COL(m))
+        b.close()
+
+    def rows_of(rowptr, col, val, N):
+        if rank is None:
+            return rowptr, col, val, 0
+        rb, re = capi.partition(N, world, rank)
+        return rowptr[rb:re + 1] - rowptr[rb], col[rowptr[rb]:rowptr[re]], val[rowptr[rb]:rowptr[re]], rb
+
+    # (a) scattered columns: every stored layout of the same matrix (halo = almost every remote row)
+    N = 90001  # (the sorted tiles want >= 2 input slices of 256 KB per shard)
+    G = _scattered(np.random.default_rng(4), N, 8)
+    G = (G + G.T + sp.diags(np.linspace(-1.0, 1.0, N))).tocsr()
+    G.sort_indices()
+    init = np.random.default_rng(8).standard_normal(N)
+    for name, cb in (("plain", 0), ("column_blocked", 4), ("sorted_tiles", -2), ("split_tiles", -3)):
+        rp, cl, vl, rb = rows_of(G.indptr.astype(np.int32), G.indices.astype(np.int32), G.data, N)
+        A = capi.Csr.upload(ctx, N, rp, cl, vl, row_begin=rb, column_blocks=cb)
+        lanczos(A, N, init, "scattered_" + name)
+        A.close()
+    # (b) complex Hermitian
+    rng = np.random.default_rng(21)
+    C0 = _scattered(rng, N, 5).tocoo()
+    C0 = sp.coo_matrix((C0.data + 1j * rng.standard_normal(C0.data.size), (C0.row, C0.col)), shape=(N, N))
+    H = (C0 + C0.conj().T).tocsr()
+    H.sort_indices()
+    rp, cl, vl, rb = rows_of(H.indptr.astype(np.int32), H.indices.astype(np.int32), H.data.astype(np.complex128), N)
+    A = capi.Csr.upload(ctx, N, rp, cl, vl, row_begin=rb)
+    lanczos(A, N, rng.standard_normal(N) + 1j * rng.standard_normal(N), "hermitian")
+    A.close()
+    # (c) dense blocks (BlockTensor layout; every rank passes all blocks, the library keeps those of its sector rows)
+    Hm = synthetic.BlockHamiltonian(30000, 10)
+    sizes, qr, qc, values, offsets = Hm.blocks()
+    A = capi.Csr.upload_blocks_raw(ctx, sizes, sizes, qr, qc, values, offsets)
+    assert A.layout() == "dense_blocks"
+    lanczos(A, Hm.N, np.random.default_rng(9).standard_normal(Hm.N), "blocks")
+    A.close()
+    return out
+
+
+def _format_worker(rank, world, port, m, out_dir, standin):
+    sys.path.insert(0, ROOT)
+    import torch  # noqa: F401
+    import torch.distributed as dist
+
+    from cmpt_eigenex_amd import capi
+
+    assert _standin_loaded() == standin
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    ids = [capi.rccl_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(ids, src=0)
+    ctx = capi.Context(device=0 if standin else rank, rank=rank, world_size=world, rccl_id=ids[0])
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **_format_runs(capi, ctx, world, rank, m))
+    ctx.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _start_ranks(target, args_of_rank, world, standin, tmp_path, timeout):
+    import multiprocessing as mp
+
+    procs = [mp.get_context("spawn").Process(target=target, args=args_of_rank(r)) for r in range(world)]
+    saved = {k: os.environ.get(k) for k in ("LD_PRELOAD", "EIGENEX_TEST_RCCL_DIR")}
+    try:
+        if standin:  # spawn: the children are fresh interpreters started with this environment
+            box = tmp_path / "standin"
+            box.mkdir()
+            os.environ["LD_PRELOAD"] = _standin_library(tmp_path)
+            os.environ["EIGENEX_TEST_RCCL_DIR"] = str(box)
+        for p in procs:
+            p.start()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    for p in procs:
+        p.join(timeout=timeout)
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+        assert p.exitcode == 0
+
+
+def test_every_operator_format_between_two_ranks(tmp_path):
+    """Plain, column-blocked, sorted-tile and split-tile CSR with scattered columns, a complex Hermitian operator and the
+    dense-block operator, each over two rank processes: alpha/beta and the last basis vector bit for bit as in the in-process
+    loopback run of the same partition."""
+    from cmpt_eigenex_amd import capi
+
+    world, m = 2, 12
+    standin = capi.device_count() < world
+    lctx = capi.Context(loopback_shards=world)
+    want = _format_runs(capi, lctx, world, None, m)
+    lctx.close()
+    port = _free_port()
+    _start_ranks(_format_worker, lambda r: (r, world, port, m, str(tmp_path), standin), world, standin, tmp_path, 600)
+    for r in range(world):
+        got = np.load(tmp_path / f"rank{r}.npz")
+        for key, v in want.items():
+            if key.startswith("rows:"):
+                v = v[slice(*capi.partition(v.shape[0], world, r))]
+            np.testing.assert_array_equal(got[key], v, err_msg=f"rank {r} {key}")
 
 
 @pytest.mark.parametrize("world,flags", [(2, []), (4, ["--halo-overlap"])])
