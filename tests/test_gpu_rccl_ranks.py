@@ -358,3 +358,46 @@ def test_bench_line_of_a_multi_rank_run_rehearsed_on_one_gpu(world, flags, tmp_p
     want_halo = [plane * ((r > 0) + (r < world - 1)) * 8 for r in range(world)]  # 1-D row shards of a 7-point stencil: a plane per side
     assert mg["halo_bytes_per_step_per_rank"] == want_halo
     assert mg["halo_overlap"] == bool(flags)
+
+
+def test_cpp_user_program_one_process_per_rank(tmp_path):
+    """tests/cpp/ranks_lanczos_amd.cpp: a C++ program on the header-only solver classes started once per rank (no MPI, no
+    torch; the communicator id travels through a file).  Two ranks agree bit for bit on the eigenvalues, each returns its own
+    rows of the Ritz vector, and both match the same program on a plain single-GPU context to fp64 round-off."""
+    import json
+    import subprocess
+
+    from cmpt_eigenex_amd import capi
+
+    exe = str(tmp_path / "ranks_lanczos_amd")
+    lib = os.path.join(ROOT, "cmpt-eigenex_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "cmpt-eigenex_amd", "include"),
+                           os.path.join(ROOT, "tests", "cpp", "ranks_lanczos_amd.cpp"), "-o", exe, "-L", lib, "-leigenex_hip", "-Wl,-rpath," + lib])
+    n, its, world = 16, 60, 2
+    single = json.loads(subprocess.check_output([exe, "0", "1", "0", str(tmp_path / "unused"), str(n), str(its)], timeout=300).decode())
+    standin = capi.device_count() < world
+    env = dict(os.environ)
+    if standin:
+        box = tmp_path / "standin"
+        box.mkdir()
+        env.update(LD_PRELOAD=_standin_library(tmp_path), EIGENEX_TEST_RCCL_DIR=str(box))
+    procs = [subprocess.Popen([exe, str(r), str(world), "0" if standin else str(r), str(tmp_path / "id"), str(n), str(its)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            so, se = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()  # exactly the processes started above
+            raise
+        assert p.returncode == 0, se.decode()[-2000:]
+        outs.append(json.loads(so.decode()))
+    assert outs[0]["eigenvalues"] == outs[1]["eigenvalues"]  # printed with %.17g: the same bits on both ranks
+    assert [o["rows"] for o in outs] == [list(capi.partition(n ** 3, world, r)) for r in range(world)]
+    assert [o["vector_rows"] for o in outs] == [o["rows"][1] - o["rows"][0] for o in outs]
+    scale = max(abs(x) for x in single["eigenvalues"])
+    np.testing.assert_allclose(outs[0]["eigenvalues"], single["eigenvalues"], rtol=0, atol=1e-10 * scale)
+    x = np.concatenate([o["first_vector"] for o in outs])
+    assert abs(np.linalg.norm(x) - 1.0) < 1e-12
+    np.testing.assert_allclose(x, single["first_vector"], rtol=0, atol=1e-7)
