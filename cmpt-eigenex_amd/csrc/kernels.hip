@@ -58,6 +58,28 @@ __device__ __forceinline__ void fin_alpha_apply(Ctrl* ctrl, double val, double* 
 
 __device__ __forceinline__ double2 ld2(const double* p) { return *reinterpret_cast<const double2*>(p); }
 __device__ __forceinline__ void st2(double* p, double2 v) { *reinterpret_cast<double2*>(p) = v; }
+typedef double v2d_st_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void nt_st2(double* p, double2 v) {
+  v2d_st_t t;
+  t.x = v.x, t.y = v.y;
+  __builtin_nontemporal_store(t, reinterpret_cast<v2d_st_t*>(p));
+}
+
+// Once-read streams -- the operator's val/col, the basis columns in k_dots / k_update / k_ritz -- use non-temporal 16-byte loads,
+// and the vectors a kernel writes in full (w in k_update, y and u in k_spmv) non-temporal stores: they do not displace the
+// operator input and the work vectors from L2 / Infinity Cache, and the HBM streams themselves run faster (r3, same box:
+// 512^3 46.99/47.42 -> 49.43/49.49 it/s with the loads, 49.67 with the stores; 128^3 4,059 -> 4,444; config 3 3,218 -> 3,349).
+// NOT the three-term inputs of load_w0 (v, u_k, u_{k-1}): measured 3 % slower in k_dots with nt.
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int4 nt_ld_i4(const int32_t* p) {
+  const v4i_t v = __builtin_nontemporal_load(reinterpret_cast<const v4i_t*>(p));
+  return make_int4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ double2 nt_ld_d2(const double* p) {
+  const v2d_t v = __builtin_nontemporal_load(reinterpret_cast<const v2d_t*>(p));
+  return make_double2(v.x, v.y);
+}
 
 __device__ __forceinline__ const double* column_ptr(const ColumnSet& cs, int ci) {
   return ci < cs.count ? cs.V + (int64_t)(cs.first + ci * cs.stride) * cs.ldv
@@ -112,7 +134,7 @@ __device__ __forceinline__ void load_col(double2 (&x)[4], const double* __restri
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int64_t row = base + i * (2 * kBlock);
-    x[i] = (FULL || row < n) ? ld2(p + row) : make_double2(0.0, 0.0);
+    x[i] = (FULL || row < n) ? nt_ld_d2(p + row) : make_double2(0.0, 0.0);
   }
 }
 
@@ -379,7 +401,7 @@ __device__ __forceinline__ double update_tile(const double* src, double* dst,  /
   for (int i = 0; i < 4; ++i) {
     const int64_t row = base + i * (2 * kBlock);
     if (FULL || row < n) {
-      st2(dst + row, w[i]);
+      nt_st2(dst + row, w[i]);
       nrm = fma(w[i].x, w[i].x, nrm);
       nrm = fma(w[i].y, w[i].y, nrm);
     }
@@ -451,19 +473,6 @@ __global__ __launch_bounds__(kBlock) void k_reduce(const double* __restrict__ pa
 // and the partial dot alpha = u.v.
 // ---------------------------------------------------------------------------
 // skew(), the chunk / lane / row-window arithmetic: spmv_index.hpp (the host replay tests/cpp/spmv_replay_host.cpp runs the same functions)
-
-// once-read streams (val/col): non-temporal 16-byte loads, so that they do not displace the operator
-// input x from L2 / Infinity Cache
-typedef int v4i_t __attribute__((ext_vector_type(4)));
-typedef double v2d_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ int4 nt_ld_i4(const int32_t* p) {
-  const v4i_t v = __builtin_nontemporal_load(reinterpret_cast<const v4i_t*>(p));
-  return make_int4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ double2 nt_ld_d2(const double* p) {
-  const v2d_t v = __builtin_nontemporal_load(reinterpret_cast<const v2d_t*>(p));
-  return make_double2(v.x, v.y);
-}
 
 // Tile schedule of a persistent SpMV workgroup.  Plain: tiles b, b+G, ...: the grid advances over the rows as one
 // frontier of G tiles per step.  XCD-sliced (flag bit 0): workgroups b and b+8 share an XCD (round-robin
@@ -691,8 +700,8 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const OFF* __restrict__ rowptr,
       const double xr = x_ext[r] * scale;
       double yr = sum;
       if (shift != 0.0) yr = add_product_nofma(yr, shift, xr);  // lanczos.hpp:390-392
-      y[r] = yr;
-      if (u_out) u_out[r] = xr;
+      __builtin_nontemporal_store(yr, &y[r]);  // results of a pass over the whole operator: nothing here reads them again
+      if (u_out) __builtin_nontemporal_store(xr, &u_out[r]);
       dot = (pass & kPassSelfNorm) ? fma(yr, yr, dot) : fma(xr, yr, dot);
     }
     rs = nrs, re = nre, p0 = np0, p1 = np1, base = nbase, tile = ntile;
@@ -884,7 +893,7 @@ __device__ __forceinline__ void split_load(SplitRegs& g, const SplitOperatorView
   g.nvalid = min(4, max(0, d.y - q));
   g.pos0 = d.z;
   if (g.nvalid > 0) {
-    g.c = *reinterpret_cast<const uint4*>(op.cp + q);
+    g.c = *reinterpret_cast<const uint4*>(op.cp + q);  // (plain: the gathers wait for it; nt measured 5 % slower)
     g.v01 = nt_ld_d2(op.val + q);
     g.v23 = nt_ld_d2(op.val + q + 2);
   }
@@ -1757,8 +1766,8 @@ __global__ __launch_bounds__(kBlock) void k_ritz(const double* __restrict__ V, i
     const double* vp = V;
 #pragma unroll 4
     for (int m = 0; m < nvec; ++m, vp += ldv) {
-      const double2 v0 = in0 ? ld2(vp + r0) : make_double2(0.0, 0.0);
-      const double2 v1 = in1 ? ld2(vp + r1) : make_double2(0.0, 0.0);
+      const double2 v0 = in0 ? nt_ld_d2(vp + r0) : make_double2(0.0, 0.0);
+      const double2 v1 = in1 ? nt_ld_d2(vp + r1) : make_double2(0.0, 0.0);
       const double* sp = St + (int64_t)m * NE;
 #pragma unroll
       for (int e = 0; e < NE; ++e) {
