@@ -58,18 +58,13 @@ __device__ __forceinline__ void fin_alpha_apply(Ctrl* ctrl, double val, double* 
 
 __device__ __forceinline__ double2 ld2(const double* p) { return *reinterpret_cast<const double2*>(p); }
 __device__ __forceinline__ void st2(double* p, double2 v) { *reinterpret_cast<double2*>(p) = v; }
-typedef double v2d_st_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void nt_st2(double* p, double2 v) {
-  v2d_st_t t;
-  t.x = v.x, t.y = v.y;
-  __builtin_nontemporal_store(t, reinterpret_cast<v2d_st_t*>(p));
-}
 
-// Once-read streams -- the operator's val/col, the basis columns in k_dots / k_update / k_ritz -- use non-temporal 16-byte loads,
+// Once-read streams -- the basis columns in k_dots / k_update / k_ritz, the split tiles' values -- use non-temporal 16-byte loads,
 // and the vectors a kernel writes in full (w in k_update, y and u in k_spmv) non-temporal stores: they do not displace the
 // operator input and the work vectors from L2 / Infinity Cache, and the HBM streams themselves run faster (r3, same box:
 // 512^3 46.99/47.42 -> 49.43/49.49 it/s with the loads, 49.67 with the stores; 128^3 4,059 -> 4,444; config 3 3,218 -> 3,349).
-// NOT the three-term inputs of load_w0 (v, u_k, u_{k-1}): measured 3 % slower in k_dots with nt.
+// NOT the three-term inputs of load_w0 (v, u_k, u_{k-1}): measured 3 % slower in k_dots with nt; and in k_spmv the val/col
+// loads are non-temporal only on request (flag bit 1): 13 % slower on the 512^3 stencil.
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef double v2d_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int4 nt_ld_i4(const int32_t* p) {
@@ -79,6 +74,11 @@ __device__ __forceinline__ int4 nt_ld_i4(const int32_t* p) {
 __device__ __forceinline__ double2 nt_ld_d2(const double* p) {
   const v2d_t v = __builtin_nontemporal_load(reinterpret_cast<const v2d_t*>(p));
   return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ void nt_st2(double* p, double2 v) {
+  v2d_t t;
+  t.x = v.x, t.y = v.y;
+  __builtin_nontemporal_store(t, reinterpret_cast<v2d_t*>(p));
 }
 
 __device__ __forceinline__ const double* column_ptr(const ColumnSet& cs, int ci) {
