@@ -303,6 +303,15 @@ def other_config(args):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ctx.profile_enable(False)
+    dt_plain = None
+    if dt / args.steps < 0.5:  # as for the Laplacian: the same steps once more without the per-launch events, reported next to `value`
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            es.compute()
+        ctx.sync()
+        torch.cuda.synchronize()
+        dt_plain = time.perf_counter() - t1
     r = es.results()
     assert r[its_from] == its, (r[its_from], its)
     prof = {k: ctx.profile_get(v) for k, v in kinds.items()}
@@ -327,6 +336,10 @@ def other_config(args):
                      "per_kernel": {k: {"launches": prof[k][0], "total_ms": prof[k][1],
                                         "gbs": (prof[k][2] / (prof[k][1] * 1e-3) / 1e9) if prof[k][1] > 0 and prof[k][2] > 0 else None} for k in prof}},
     }
+    if dt_plain is not None:
+        out["without_per_launch_events"] = {"value": args.steps * its / dt_plain, "ms_per_step": dt_plain / args.steps * 1e3,
+                                            "hbm_roofline_frac_whole_step": total_bytes * args.steps / dt_plain / 1e9 / HBM_PEAK_GBS,
+                                            "note": "the same steps repeated with the per-launch HIP events off"}
     if not args.no_cpu_baseline:
         from oracle import cref
         from oracle import krylov_oracle as ko
