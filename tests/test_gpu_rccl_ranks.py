@@ -326,9 +326,9 @@ def test_every_operator_format_between_two_ranks(tmp_path):
             np.testing.assert_array_equal(got[key], v, err_msg=f"rank {r} {key}")
 
 
-@pytest.mark.parametrize("world,flags", [(2, []), (4, ["--halo-overlap"])])
-def test_bench_line_of_a_multi_rank_run_rehearsed_on_one_gpu(world, flags, tmp_path):
-    """bench.py --gpus N end to end with N real rank processes on a box with fewer GPUs: its own launcher, the process group,
+@pytest.mark.parametrize("world,flags,launcher", [(2, [], "own"), (4, ["--halo-overlap"], "own"), (2, [], "torchrun")])
+def test_bench_line_of_a_multi_rank_run_rehearsed_on_one_gpu(world, flags, launcher, tmp_path):
+    """bench.py --gpus N end to end with N real rank processes on a box with fewer GPUs: its own launcher or torch.distributed.run, the process group,
     the id broadcast, the sharded stencil with its neighbour exchange, max-over-ranks timing and the multi_gpu block -- with
     BENCH_REHEARSAL=1 (ranks share device 0, gloo process group) and the stand-in transport preloaded.  What is checked is
     that the run completes and that the line describes N ranks with the right shards; its rate is not a measurement."""
@@ -343,8 +343,14 @@ def test_bench_line_of_a_multi_rank_run_rehearsed_on_one_gpu(world, flags, tmp_p
     box.mkdir()
     env = dict(os.environ, LD_PRELOAD=_standin_library(tmp_path), EIGENEX_TEST_RCCL_DIR=str(box), BENCH_REHEARSAL="1")
     n, m = 40, 12
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--n", str(n), "--m", str(m), "--steps", "2",
-                          "--warmup", "1", *flags], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    # (full option names: torch.distributed.run's parser rejects abbreviations such as --n as ambiguous even behind the script path)
+    bench = [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--grid-edge", str(n), "--krylov-steps", str(m), "--steps", "2", "--warmup", "1", *flags]
+    if launcher == "torchrun":  # the command line the driver uses for N > 1
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), *bench]
+    else:  # bench.py starts its own ranks
+        cmd = [sys.executable, *bench]
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert out.returncode == 0, out.stderr.decode()[-4000:]
     lines = [ln for ln in out.stdout.decode().splitlines() if ln.strip()]
     assert len(lines) == 1, lines  # exactly one line on stdout
