@@ -248,7 +248,32 @@ def _format_runs(capi, ctx, world, rank, m):
     H.sort_indices()
     rp, cl, vl, rb = rows_of(H.indptr.astype(np.int32), H.indices.astype(np.int32), H.data.astype(np.complex128), N)
     A = capi.Csr.upload(ctx, N, rp, cl, vl, row_begin=rb)
-    lanczos(A, N, rng.standard_normal(N) + 1j * rng.standard_normal(N), "hermitian")
+    zinit = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    lanczos(A, N, zinit, "hermitian")
+    # complex Ritz vectors: the phase of a vector's first non-zero entry is found across ranks (all-gather) before every rank divides by it
+    from cmpt_eigenex_amd import solver
+
+    es = solver.LanczosEigenSolver(np.complex128)
+    es.setDeviceOperator(A).set(minIterations=2 * m, maxIterations=2 * m, maxEigenvalues=2, initialVector=zinit)
+    es.compute()
+    r = es.results()
+    out["hermitian_solver_values"] = np.asarray(r["eigenvalues"])
+    out["rows:hermitian_solver_vectors"] = np.asarray(r["eigenvectors"])
+    es.close()
+    A.close()
+    # real non-symmetric operator, Arnoldi: complex Ritz vectors from a real basis
+    Gn = _scattered(np.random.default_rng(31), N, 6)
+    Gn = (Gn + sp.diags(np.linspace(1.0, 2.0, N))).tocsr()
+    Gn.sort_indices()
+    rp, cl, vl, rb = rows_of(Gn.indptr.astype(np.int32), Gn.indices.astype(np.int32), Gn.data, N)
+    A = capi.Csr.upload(ctx, N, rp, cl, vl, row_begin=rb)
+    ar = solver.ArnoldiEigenSolver()
+    ar.setDeviceOperator(A).set(minIterations=2 * m, maxIterations=2 * m, maxEigenvalues=3, initialVector=init)
+    ar.compute()
+    r = ar.results()
+    out["arnoldi_solver_values"] = np.asarray(r["eigenvalues"])
+    out["rows:arnoldi_solver_vectors"] = np.asarray(r["eigenvectors"])
+    ar.close()
     A.close()
     # (c) dense blocks (BlockTensor layout; every rank passes all blocks, the library keeps those of its sector rows)
     Hm = synthetic.BlockHamiltonian(30000, 10)
