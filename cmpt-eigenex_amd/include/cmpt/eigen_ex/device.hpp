@@ -86,6 +86,13 @@ class CsrOperator {
       : ctx_(std::move(ctx)), n_(n_global) {
     check(eigenex_csr_upload64(ctx_->handle(), n_global, row_begin, n_rows, rowptr, col_global, val, &h_), "eigenex_csr_upload64");
   }
+  // fp32 values (a Scalar = float user's matrix): widened here, the device stores and multiplies in fp64
+  CsrOperator(std::shared_ptr<Context> ctx, std::int64_t n_global, std::int64_t row_begin, std::int64_t n_rows,
+              const std::int32_t* rowptr, const std::int32_t* col_global, const float* val)
+      : ctx_(std::move(ctx)), n_(n_global) {
+    const std::vector<double> wide(val, val + (n_rows > 0 ? rowptr[n_rows] - rowptr[0] : 0));
+    check(eigenex_csr_upload(ctx_->handle(), n_global, row_begin, n_rows, rowptr, col_global, wide.data(), &h_), "eigenex_csr_upload");
+  }
   // complex values (std::complex<double>, crossing the C ABI as interleaved doubles)
   static std::shared_ptr<CsrOperator> complexCsr(std::shared_ptr<Context> ctx, std::int64_t n_global, std::int64_t row_begin,
                                                  std::int64_t n_rows, const std::int32_t* rowptr,

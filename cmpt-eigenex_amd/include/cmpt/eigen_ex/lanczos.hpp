@@ -13,7 +13,8 @@
 //     called on the host with host pointers, exactly as in the reference, while the
 //     vector work stays on the GPU (the vector is staged through pinned memory).
 //   * info(): Eigen-style status derived from the same events the reference logs.
-//   * Scalar = double or std::complex<double> (the two instantiations the reference's samples use).
+//   * Scalar = double or std::complex<double> (the two instantiations the reference's samples use); float and std::complex<float> are
+//     accepted at the API and computed in fp64 on the device (detail::Wide below).
 //   * VectorType/MatrixType are cmpt::EigenEx::DenseVector/DenseMatrix (dense.hpp),
 //     convertible from/to Eigen types when Eigen is present.
 //   * es_tri() (an Eigen solver object) is replaced by tridiagonalEigenvalues() /
@@ -73,8 +74,87 @@ inline double makeScalar<double>(double re, double) { return re; }
 template <>
 inline std::complex<double> makeScalar<std::complex<double>>(double re, double im) { return std::complex<double>(re, im); }
 
+// fp32 scalars (float, std::complex<float>: the reference's DefaultTolerance<float>, lanczos.hpp:70-73) are accepted at the API.
+// The device path is fp64 throughout: such data are widened on their way to the C ABI and rounded once on their way back, so a
+// Scalar = float solver returns what the reference's float arithmetic approximates, at least as accurately.  Not a float kernel path.
 template <class S>
-struct SupportedScalar : std::integral_constant<bool, std::is_same<S, double>::value || std::is_same<S, std::complex<double>>::value> {};
+struct Wide {
+  using type = S;
+};
+template <>
+struct Wide<float> {
+  using type = double;
+};
+template <>
+struct Wide<std::complex<float>> {
+  using type = std::complex<double>;
+};
+template <class S>
+struct IsNarrow : std::integral_constant<bool, !std::is_same<S, typename Wide<S>::type>::value> {};
+
+// n scalars read by the C ABI as doubles ((re, im) pairs for complex): the caller's memory itself for fp64 types, a widened copy otherwise
+template <class S, bool Narrow = IsNarrow<S>::value>
+class WideIn {
+ public:
+  WideIn(const S* p, Index) : p_(p) {}
+  const double* data() const { return reinterpret_cast<const double*>(p_); }
+
+ private:
+  const S* p_;
+};
+template <class S>
+class WideIn<S, true> {
+ public:
+  WideIn(const S* p, Index n) : b_(p, p + (n < 0 ? 0 : n)) {}
+  const double* data() const { return reinterpret_cast<const double*>(b_.data()); }
+
+ private:
+  std::vector<typename Wide<S>::type> b_;
+};
+// n scalars written by the C ABI as doubles: straight into the caller's memory for fp64 types, through a buffer that is rounded into
+// it when the object goes out of scope otherwise
+template <class S, bool Narrow = IsNarrow<S>::value>
+class WideOut {
+ public:
+  WideOut(S* p, Index) : p_(p) {}
+  double* data() { return reinterpret_cast<double*>(p_); }
+
+ private:
+  S* p_;
+};
+template <class S>
+class WideOut<S, true> {
+ public:
+  WideOut(S* p, Index n) : p_(p), b_(static_cast<std::size_t>(n < 0 ? 0 : n)) {}
+  WideOut(const WideOut&) = delete;
+  WideOut& operator=(const WideOut&) = delete;
+  ~WideOut() {
+    for (std::size_t i = 0; i < b_.size(); ++i) p_[i] = static_cast<S>(b_[i]);
+  }
+  double* data() { return reinterpret_cast<double*>(b_.data()); }
+
+ private:
+  S* p_;
+  std::vector<typename Wide<S>::type> b_;
+};
+
+// coefficient series are kept in fp64 (what the device computed); the accessors of an fp32 solver show a rounded copy
+inline const std::vector<double>& apiView(const std::vector<double>& wide, std::vector<double>&) { return wide; }
+inline const std::vector<float>& apiView(const std::vector<double>& wide, std::vector<float>& cache) {
+  cache.assign(wide.begin(), wide.end());
+  return cache;
+}
+
+template <>
+inline float makeScalar<float>(double re, double) { return static_cast<float>(re); }
+template <>
+inline std::complex<float> makeScalar<std::complex<float>>(double re, double im) {
+  return std::complex<float>(static_cast<float>(re), static_cast<float>(im));
+}
+
+template <class S>
+struct SupportedScalar : std::integral_constant<bool, std::is_same<S, double>::value || std::is_same<S, std::complex<double>>::value ||
+                                                        std::is_same<S, float>::value || std::is_same<S, std::complex<float>>::value> {};
 
 // one draw per entry for real scalars; real part then imaginary part for complex ones
 // (reference util.hpp:76-97 ComplexNormalDistribution, util.hpp:132-148 NormalDistributionGen)
@@ -88,6 +168,16 @@ inline void drawGaussian(std::normal_distribution<double>& d, URBG& g, std::comp
   const double im = d(g);
   out = std::complex<double>(re, im);
 }
+template <class URBG>
+inline void drawGaussian(std::normal_distribution<double>& d, URBG& g, float& out) {
+  out = static_cast<float>(d(g));
+}
+template <class URBG>
+inline void drawGaussian(std::normal_distribution<double>& d, URBG& g, std::complex<float>& out) {
+  const double re = d(g);
+  const double im = d(g);
+  out = std::complex<float>(static_cast<float>(re), static_cast<float>(im));
+}
 
 // normalised Gaussian vector: reference random.hpp:89-101
 template <class S, class URBG>
@@ -95,18 +185,37 @@ inline DenseVector<S> gaussianUnitVector(URBG& g, Index size) {
   std::normal_distribution<double> dist;
   DenseVector<S> v(size < 0 ? 0 : size);
   for (Index i = 0; i < v.size(); ++i) drawGaussian(dist, g, v[i]);
-  const double nrm = v.norm();
-  if (nrm > 0.0)
+  const typename RealOf<S>::type nrm = v.norm();
+  if (nrm > 0)
     for (Index i = 0; i < v.size(); ++i) v[i] /= nrm;
   return v;
 }
 
 // std::function operator -> C callback; complex data cross the C ABI as interleaved doubles
-template <class S>
+template <class S, bool Narrow = IsNarrow<S>::value>
 struct HostOperatorThunk {
   std::function<void(const S*, S*)> fn;
+  Index n = 0;
   static void call(const double* in, double* out, void* user) {
     static_cast<HostOperatorThunk*>(user)->fn(reinterpret_cast<const S*>(in), reinterpret_cast<S*>(out));
+  }
+};
+// fp32 callback: the vector is rounded for the user's function and its result widened again
+template <class S>
+struct HostOperatorThunk<S, true> {
+  std::function<void(const S*, S*)> fn;
+  Index n = 0;
+  std::vector<S> in32, out32;
+  static void call(const double* in, double* out, void* user) {
+    HostOperatorThunk* t = static_cast<HostOperatorThunk*>(user);
+    using W = typename Wide<S>::type;
+    const W* win = reinterpret_cast<const W*>(in);
+    W* wout = reinterpret_cast<W*>(out);
+    t->in32.resize(static_cast<std::size_t>(t->n));
+    t->out32.assign(static_cast<std::size_t>(t->n), S());
+    for (Index i = 0; i < t->n; ++i) t->in32[static_cast<std::size_t>(i)] = static_cast<S>(win[i]);
+    t->fn(t->in32.data(), t->out32.data());
+    for (Index i = 0; i < t->n; ++i) wout[i] = static_cast<W>(t->out32[static_cast<std::size_t>(i)]);
   }
 };
 
@@ -178,17 +287,23 @@ class KrylovDevice {
   Index localRows() const { return n_rows_; }
   // host vector of global or local length -> pointer to the local rows
   template <class S>
-  const double* localSlice(const DenseVector<S>& v) const {
-    if (v.size() == n_rows_) return reinterpret_cast<const double*>(v.data());
-    if (v.size() == n_global_) return reinterpret_cast<const double*>(v.data() + row_begin_);
+  const S* localSlice(const DenseVector<S>& v) const {
+    if (v.size() == n_rows_) return v.data();
+    if (v.size() == n_global_) return v.data() + row_begin_;
     throw LanczosException("vector length matches neither the matrix height nor this rank's row count");
   }
   template <class S>
-  void upload(int ref, const DenseVector<S>& v) { device::check(eigenex_vec_upload(basis_, ref, localSlice(v)), "eigenex_vec_upload"); }
+  void upload(int ref, const DenseVector<S>& v) {
+    const WideIn<S> w(localSlice(v), n_rows_);
+    device::check(eigenex_vec_upload(basis_, ref, w.data()), "eigenex_vec_upload");
+  }
   template <class S>
   DenseVector<S> download(int ref) const {
     DenseVector<S> v(n_rows_);
-    device::check(eigenex_vec_download(basis_, ref, reinterpret_cast<double*>(v.data())), "eigenex_vec_download");
+    {
+      WideOut<S> w(v.data(), n_rows_);
+      device::check(eigenex_vec_download(basis_, ref, w.data()), "eigenex_vec_download");
+    }
     return v;
   }
 
@@ -206,12 +321,12 @@ class KrylovDevice {
 // ---------------------------------------------------------------------------
 template <class Scalar_>
 class LanczosBase {
-  static_assert(detail::SupportedScalar<Scalar_>::value, "cmpt-eigenex_amd: Scalar must be double or std::complex<double>");
+  static_assert(detail::SupportedScalar<Scalar_>::value, "cmpt-eigenex_amd: Scalar must be double, std::complex<double>, float or std::complex<float>");
 
  public:
   using Index = EigenEx::Index;
   using Scalar = Scalar_;
-  using RealScalar = double;
+  using RealScalar = typename RealOf<Scalar_>::type;
   using VectorType = DenseVector<Scalar>;
   using RealVectorType = DenseVector<RealScalar>;
   using MatrixType = DenseMatrix<Scalar>;
@@ -328,8 +443,11 @@ class LanczosBase {
   }
   // number of basis vectors without downloading them
   Index lanczosvectorsSize() const { return nvec_; }
-  const std::vector<RealScalar>& alpha() const { return alpha_; }
-  const std::vector<RealScalar>& beta() const { return beta_; }
+  const std::vector<RealScalar>& alpha() const { return detail::apiView(alpha_, alphaApi_); }
+  const std::vector<RealScalar>& beta() const { return detail::apiView(beta_, betaApi_); }
+  // the same series as the device computed them (fp64 whatever the Scalar)
+  const std::vector<double>& alphaWide() const { return alpha_; }
+  const std::vector<double>& betaWide() const { return beta_; }
 
   LanczosBase() { setAllSettingsDefault(); }
   // copyable and movable like the reference's class (implicit copy, lanczos.hpp:104-105): a copy owns a deep copy of
@@ -434,11 +552,17 @@ class LanczosBase {
   // Ritz vectors X = V S on the GPU, normalised and phase-fixed (reference :798-816);
   // S is column-major lanczosvectors().size() x nev
   MatrixType ritzVectors(const RealScalar* S, Index lds, Index nev) const {
+    const detail::WideIn<RealScalar> s(S, lds * nev);
+    return ritzVectorsWide(s.data(), lds, nev);
+  }
+  // the same with fp64 coefficients whatever the Scalar (what the front-ends hold)
+  MatrixType ritzVectorsWide(const double* S, Index lds, Index nev) const {
     MatrixType X(dev_.alive() ? dev_.localRows() : matrixHeight_, nev);
-    if (nev > 0 && nvec_ > 0)
-      device::check(eigenex_ritz_vectors(dev_.handle(), static_cast<int>(nvec_), static_cast<int>(nev), S, static_cast<int>(lds),
-                                         reinterpret_cast<double*>(X.data()), X.rows()),
+    if (nev > 0 && nvec_ > 0) {
+      detail::WideOut<Scalar> x(X.data(), X.size());
+      device::check(eigenex_ritz_vectors(dev_.handle(), static_cast<int>(nvec_), static_cast<int>(nev), S, static_cast<int>(lds), x.data(), X.rows()),
                     "eigenex_ritz_vectors");
+    }
     return X;
   }
 
@@ -462,14 +586,16 @@ class LanczosBase {
 
  protected:
   void combine_(const Scalar* c, Index count, VectorType& out, std::false_type) const {
-    device::check(eigenex_krylov_combine(dev_.handle(), static_cast<int>(count), 1, c, nullptr, static_cast<int>(count), out.data(), out.size()),
+    const detail::WideIn<Scalar> cw(c, count);
+    detail::WideOut<Scalar> o(out.data(), out.size());
+    device::check(eigenex_krylov_combine(dev_.handle(), static_cast<int>(count), 1, cw.data(), nullptr, static_cast<int>(count), o.data(), out.size()),
                   "eigenex_krylov_combine");
   }
   void combine_(const Scalar* c, Index count, VectorType& out, std::true_type) const {
     std::vector<double> re(static_cast<std::size_t>(count)), im(static_cast<std::size_t>(count));
     for (Index m = 0; m < count; ++m) re[static_cast<std::size_t>(m)] = std::real(c[m]), im[static_cast<std::size_t>(m)] = std::imag(c[m]);
-    device::check(eigenex_krylov_combine(dev_.handle(), static_cast<int>(count), 1, re.data(), im.data(), static_cast<int>(count),
-                                         reinterpret_cast<double*>(out.data()), out.size()),
+    detail::WideOut<Scalar> o(out.data(), out.size());
+    device::check(eigenex_krylov_combine(dev_.handle(), static_cast<int>(count), 1, re.data(), im.data(), static_cast<int>(count), o.data(), out.size()),
                   "eigenex_krylov_combine");
   }
   std::shared_ptr<device::Context> contextOrDefault_() {
@@ -493,6 +619,7 @@ class LanczosBase {
     }
     if (!deviceOperator_) {
       thunk_.fn = matrixMultiplication_;
+      thunk_.n = matrixHeight_;
       device::check(eigenex_basis_set_host_operator(dev_.handle(), &detail::HostOperatorThunk<Scalar>::call, &thunk_), "eigenex_basis_set_host_operator");
     }
     device::check(eigenex_basis_configure(dev_.handle(), eigenvalueShift_, threshold_, reorthogonalizeInterval_, static_cast<int>(ortho_)),
@@ -599,7 +726,8 @@ class LanczosBase {
   // computed data visible to the caller
   Index iterations_ = 0;
   Index nvec_ = 0;
-  std::vector<RealScalar> alpha_, beta_;
+  std::vector<double> alpha_, beta_;
+  mutable std::vector<RealScalar> alphaApi_, betaApi_;  // only used when RealScalar is not double
   mutable std::vector<VectorType> vectorCache_;
 
   // device side
@@ -629,7 +757,7 @@ class LanczosEigenSolver {
  public:
   using Index = EigenEx::Index;
   using Scalar = Scalar_;
-  using RealScalar = double;
+  using RealScalar = typename RealOf<Scalar_>::type;
   using VectorType = DenseVector<Scalar>;
   using RealVectorType = DenseVector<RealScalar>;
   using MatrixType = DenseMatrix<Scalar>;
@@ -774,12 +902,12 @@ class LanczosEigenSolver {
   // spectrum / eigenvectors of the current tridiagonal matrix (stand-in for es_tri())
   const std::vector<RealScalar>& tridiagonalEigenvalues() const {
     if (triStale_) const_cast<LanczosEigenSolver*>(this)->solveTridiagonal_();
-    return triValues_;
+    return detail::apiView(triValues_, triApi_);
   }
   RealMatrixType tridiagonalEigenvectors() const {
     std::vector<double> vals, vecs;
     const Index n = static_cast<Index>(lanczosBase_.alpha().size());
-    small_eigen::tridiagonal(lanczosBase_.alpha().data(), lanczosBase_.beta().data(), static_cast<int>(n), vals, &vecs);
+    small_eigen::tridiagonal(lanczosBase_.alphaWide().data(), lanczosBase_.betaWide().data(), static_cast<int>(n), vals, &vecs);
     RealMatrixType m(n, n);
     std::copy(vecs.begin(), vecs.end(), m.data());
     return m;
@@ -873,8 +1001,8 @@ class LanczosEigenSolver {
   }
 
   void solveTridiagonal_() {
-    const auto& a = lanczosBase_.alpha();
-    const auto& b = lanczosBase_.beta();
+    const auto& a = lanczosBase_.alphaWide();
+    const auto& b = lanczosBase_.betaWide();
     small_eigen::tridiagonal(a.data(), b.data(), static_cast<int>(a.size()), triValues_, nullptr);
     triStale_ = false;
   }
@@ -945,7 +1073,7 @@ class LanczosEigenSolver {
       // solve and half of a 64^3 one.
       if (stepped && lanczosBase_.iterations() + 1 < minIterations_ && !lanczosBase_.lanczosStepIsUtmost()) {
         triStale_ = true;
-        triValues_.assign(lanczosBase_.alpha().size(), RealScalar(0.0));  // size only
+        triValues_.assign(lanczosBase_.alphaWide().size(), 0.0);  // size only
       } else {
         solveTridiagonal_();
       }
@@ -962,8 +1090,8 @@ class LanczosEigenSolver {
       // X = V S, normalised, first non-zero entry made positive: one pass over V per 8 vectors, on the GPU
       std::vector<double> vals, vecs;
       const Index m = static_cast<Index>(lanczosBase_.alpha().size());
-      small_eigen::tridiagonal(lanczosBase_.alpha().data(), lanczosBase_.beta().data(), static_cast<int>(m), vals, &vecs);
-      eigenvectors_ = lanczosBase_.ritzVectors(vecs.data(), m, eivalsize);
+      small_eigen::tridiagonal(lanczosBase_.alphaWide().data(), lanczosBase_.betaWide().data(), static_cast<int>(m), vals, &vecs);
+      eigenvectors_ = lanczosBase_.ritzVectorsWide(vecs.data(), m, eivalsize);
     } else {
       eigenvectors_.resize(0, 0);
     }
@@ -1015,7 +1143,8 @@ class LanczosEigenSolver {
   RealVectorType eigenvalues_;
   MatrixType eigenvectors_;
   std::vector<std::string> log_;
-  std::vector<RealScalar> triValues_;
+  std::vector<double> triValues_;
+  mutable std::vector<RealScalar> triApi_;  // only used when RealScalar is not double
   bool triStale_ = false;  // triValues_ has the right size but no values (deferred solve)
   struct Deferred {
     Index index;           // key in convergenceLog_
@@ -1031,7 +1160,7 @@ class LanczosEigenSolver {
     std::vector<double> vals;
     for (const Deferred& d : deferredLog_) {
       if (d.size != solved) {
-        small_eigen::tridiagonal(lanczosBase_.alpha().data(), lanczosBase_.beta().data(), static_cast<int>(d.size), vals, nullptr);
+        small_eigen::tridiagonal(lanczosBase_.alphaWide().data(), lanczosBase_.betaWide().data(), static_cast<int>(d.size), vals, nullptr);
         solved = d.size;
       }
       convergenceLog_[d.index][d.position] = vals[static_cast<std::size_t>(d.formal)];

@@ -99,9 +99,14 @@ class LanczosFunctionSolver {
     if (ctx->shardsTotal() != 1) throw LanczosException("explicit-eigenpair expansion needs an unsharded context");
     detail::VectorWorkspace<Scalar> ws(ctx, nullptr, n, static_cast<int>(max));
     constexpr int es = detail::IsComplex<Scalar>::value ? 2 : 1;
-    for (Index c = 0; c < max; ++c)
-      device::check(eigenex_vec_upload(ws.handle(), EIGENEX_VEC_COL(static_cast<int>(c)), reinterpret_cast<const double*>(eivecs.data() + c * eivecs.rows())), "eigenex_vec_upload");
-    device::check(eigenex_vec_upload(ws.handle(), EIGENEX_VEC_V, reinterpret_cast<const double*>(in.data())), "eigenex_vec_upload");
+    for (Index c = 0; c < max; ++c) {
+      const detail::WideIn<Scalar> col(eivecs.data() + c * eivecs.rows(), n);
+      device::check(eigenex_vec_upload(ws.handle(), EIGENEX_VEC_COL(static_cast<int>(c)), col.data()), "eigenex_vec_upload");
+    }
+    {
+      const detail::WideIn<Scalar> v(in.data(), n);
+      device::check(eigenex_vec_upload(ws.handle(), EIGENEX_VEC_V, v.data()), "eigenex_vec_upload");
+    }
     std::vector<double> h(static_cast<std::size_t>(max) * es, 0.0);
     device::check(eigenex_dots(ws.handle(), EIGENEX_VEC_V, 0, 1, static_cast<int>(max), 0, h.data()), "eigenex_dots");  // x_n^H in
     // the terms are added in the reference's order: the update subtracts its columns one after the other
@@ -120,7 +125,8 @@ class LanczosFunctionSolver {
       for (Index k = 0; k < max; ++k)
         device::check(eigenex_update(ws.handle(), EIGENEX_VEC_V, static_cast<int>(max - k - 1), 1, 1, 0, neg.data() + static_cast<std::size_t>(k) * es, &nrm2), "eigenex_update");
     }
-    device::check(eigenex_vec_download(ws.handle(), EIGENEX_VEC_V, reinterpret_cast<double*>(out.data())), "eigenex_vec_download");
+    detail::WideOut<Scalar> o(out.data(), n);
+    device::check(eigenex_vec_download(ws.handle(), EIGENEX_VEC_V, o.data()), "eigenex_vec_download");
   }
 };
 

@@ -444,3 +444,46 @@ def test_hot_kernels_keep_their_registers():
     assert vgprs("6k_spmvILb0EiE") <= 64           # k_spmv<short rows, int32 row pointers>
     assert vgprs("6k_spmvILb0ElE") <= 64           # ... int64 row pointers
     assert vgprs("12k_block_spmvE") <= 84          # six waves per SIMD
+
+
+def test_solver_classes_instantiate_for_all_four_scalars(tmp_path):
+    """double, std::complex<double>, float, std::complex<float>: every front-end compiles (syntax only: no GPU, nothing runs)"""
+    import shutil
+    import subprocess
+
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    src = tmp_path / "inst.cpp"
+    src.write_text("""
+#include "cmpt/eigen_ex/arnoldi.hpp"
+#include "cmpt/eigen_ex/lanczos.hpp"
+#include "cmpt/eigen_ex/lanczos_function.hpp"
+#include "cmpt/eigen_ex/thick_restart_lanczos.hpp"
+using namespace cmpt::EigenEx;
+template <class S>
+void use() {
+  LanczosEigenSolver<S> es;
+  es.setMatrixMultiplication([](const S*, S*) {}, 10).setTolerance(1e-4).setMaxIterations(5).setMaxEigenvalues(2);
+  es.compute();
+  (void)es.eigenvalues(); (void)es.eigenvectors(); (void)es.lanczosvectors(); (void)es.alpha(); (void)es.beta(); (void)es.info();
+  (void)es.es_tri().eigenvalues(); (void)es.es_tri().eigenvectors(); (void)es.convergenceLog();
+  es.continueToCompute();
+  ArnoldiEigenSolver<S> ar;
+  ar.setMatrixMultiplication([](const S*, S*) {}, 10).setMaxIterations(5);
+  ar.compute();
+  (void)ar.eigenvalues(); (void)ar.eigenvectors(); (void)ar.hessenbergMatrix(); (void)ar.arnoldivectors(); (void)ar.des().eigenvalues();
+  ThickRestartLanczosEigenSolver<S> tr;
+  tr.setMatrixMultiplication([](const S*, S*) {}, 10);
+  tr.compute();
+  (void)tr.eigenvalues(); (void)tr.eigenvectors();
+  DenseVector<S> in(10), out;
+  LanczosFunctionSolver<S>::solve([](S x) { return x; }, es);
+}
+template void use<double>();
+template void use<std::complex<double>>();
+template void use<float>();
+template void use<std::complex<float>>();
+int main() {}
+""")
+    subprocess.check_call(["g++", "-std=c++11", "-fsyntax-only", "-Wall", "-I", os.path.join(ROOT, "include"), "-I",
+                           os.path.join(ROOT, "cmpt-eigenex_amd", "include"), str(src)])

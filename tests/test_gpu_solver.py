@@ -600,3 +600,29 @@ def test_cpp_program_copy_semantics_and_small_solver_views(tmp_path):
     out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert out.returncode == 0, (out.stdout + out.stderr).decode()[-3000:]
     assert b"all checks passed" in out.stdout
+
+
+def test_cpp_program_float_and_complex_float_scalars(tmp_path):
+    """Scalar = float / std::complex<float> (the reference's DefaultTolerance<float>, lanczos.hpp:70-73) through the header-only
+    classes: fp32 data in and out, fp64 on the device.  Known spectra: 2 - 2 cos(k pi / (n+1)) and the reference's second sample,
+    2 cos(k pi / (n+1)); parity of these instantiations with the reference is unpinned (no reference sample uses them)."""
+    exe = str(tmp_path / "float_scalar_amd")
+    lib = os.path.join(ROOT, "cmpt-eigenex_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "cmpt-eigenex_amd", "include"),
+                           os.path.join(ROOT, "tests", "cpp", "float_scalar_amd.cpp"), "-o", exe, "-L", lib, "-leigenex_hip", "-Wl,-rpath," + lib])
+    out = json.loads(subprocess.check_output([exe], timeout=300).decode())
+    n = 200
+    k = np.arange(1, n + 1)
+    real_spectrum = 2.0 - 2.0 * np.cos(k * np.pi / (n + 1))
+    eps32 = float(np.finfo(np.float32).eps)
+    assert abs(out["float_default_tolerance"] - 1e-4) < 1e-10 and out["float_info"] == 0  # DefaultTolerance<float>
+    # the tolerance-driven run stops where the reference's relative-change test at 1e-4 stops it; what it returns is a Ritz pair of the
+    # Krylov space it built: residual within the Ritz value's own accuracy, unit vector
+    assert out["float_host_residual"] < 0.1 and abs(out["float_host_vector_norm"] - 1.0) < 1e-6
+    # full Krylov space: the lowest eigenvalues up to fp32 rounding of inputs and outputs (spectral width 4)
+    np.testing.assert_allclose(out["float_device_values"], real_spectrum[:5], rtol=0, atol=16 * eps32)
+    assert out["float_thick_restart_info"] == 0
+    np.testing.assert_allclose(out["float_thick_restart_values"], real_spectrum[:3], rtol=0, atol=16 * eps32)
+    np.testing.assert_allclose(out["complex_float_values"], np.sort(2.0 * np.cos(k * np.pi / (n + 1)))[:4], rtol=0, atol=16 * eps32)
+    assert out["complex_float_residual"] < 1e-5 and abs(out["complex_float_first_entry_imag"]) < 1e-7  # phase-fixed Ritz vector
+    assert out["arnoldi_float"]["n"] == 6 and out["arnoldi_float"]["max_residual"] < 1e-5
