@@ -556,7 +556,7 @@ __device__ __forceinline__ void arnoldi_begin_record(const InlineArnoldiBegin& a
 // int64_t (r3; the reference's Index is 64-bit, lanczos.hpp:108-116): the offsets of a TILE are taken relative to the tile's
 // first entry rounded down to a multiple of 4 -- `base`, which moves the col / val pointers -- so that everything behind the
 // row-pointer loads is the same 32-bit arithmetic (spmv_index.hpp) for both types; with int32_t the base is the constant 0.
-template <bool LONG_ROWS, class OFF>
+template <bool LONG_ROWS, class OFF, bool NT>
 __global__ __launch_bounds__(kBlock) void k_spmv(const OFF* __restrict__ rowptr, const int32_t* __restrict__ col_all,
                                                  const double* __restrict__ val_all, const double* __restrict__ x_ext,
                                                  const double* __restrict__ scale_ptr, double shift,
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const OFF* __restrict__ rowptr,
   }
   const int tid = threadIdx.x;
   double dot = 0.0;
-  const bool nt = (spmv_flags & 2) != 0;  // flags: bit 0 = XCD-contiguous tiles, bit 1 = non-temporal val/col loads
+  constexpr bool nt = NT;  // flags: bit 0 = XCD-contiguous tiles, bit 1 = cache policy of the val/col streams (NT, chosen by the launcher)
   const TileRange tr = spmv_tiles(ntiles, spmv_flags & 1);
   // row pointers of a tile: fetched one tile ahead, so that their latency is not part of the chain
   // rowptr -> val/col -> x that every tile otherwise pays in sequence
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(kBlock) void k_spmv(const OFF* __restrict__ rowptr,
       const bool in0 = ll.in0, in1 = ll.in1;
       int4 ca = make_int4(0, 0, 0, 0), cbv = make_int4(0, 0, 0, 0);
       double2 a01 = make_double2(0.0, 0.0), a23 = a01, b01 = a01, b23 = a01;
-      if (nt) {  // wave-uniform
+      if (nt) {  // compile-time: a run-time branch here cost the plain path 6-8 % through its register allocation (r3)
         if (in0) {
           ca = nt_ld_i4(col + q0);
           a01 = nt_ld_d2(val + q0);
@@ -1973,12 +1973,18 @@ static void launch_spmv_t(hipStream_t s, const OFF* rowptr, const int32_t* col, 
   if (ntiles <= 0) return;
   const InlineFin nofin{nullptr, 0, 0, 0.0, nullptr, nullptr, nullptr};
   const InlineArnoldiBegin nobegin{nullptr, 0.0, 0, 0, nullptr, 0, 0, -1, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
-  if (spmv_flags & 4)  // bit 2: long rows
-    hipLaunchKernelGGL((k_spmv<true, OFF>), dim3(grid), dim3(kBlock), 0, s, rowptr, col, val, x_ext, scale, shift, y, u_out, n,
-                       ntiles, partials, spmv_flags, pass, ctrl, fin ? *fin : nofin, begin ? *begin : nobegin, tile_list);
-  else
-    hipLaunchKernelGGL((k_spmv<false, OFF>), dim3(grid), dim3(kBlock), 0, s, rowptr, col, val, x_ext, scale, shift, y, u_out, n,
-                       ntiles, partials, spmv_flags, pass, ctrl, fin ? *fin : nofin, begin ? *begin : nobegin, tile_list);
+  const bool nt = (spmv_flags & 2) != 0;
+#define EIGENEX_LAUNCH_SPMV(LONG, NTV)                                                                                              \
+  hipLaunchKernelGGL((k_spmv<LONG, OFF, NTV>), dim3(grid), dim3(kBlock), 0, s, rowptr, col, val, x_ext, scale, shift, y, u_out, n, \
+                     ntiles, partials, spmv_flags, pass, ctrl, fin ? *fin : nofin, begin ? *begin : nobegin, tile_list)
+  if (spmv_flags & 4) {  // bit 2: long rows
+    if (nt) EIGENEX_LAUNCH_SPMV(true, true);
+    else EIGENEX_LAUNCH_SPMV(true, false);
+  } else {
+    if (nt) EIGENEX_LAUNCH_SPMV(false, true);
+    else EIGENEX_LAUNCH_SPMV(false, false);
+  }
+#undef EIGENEX_LAUNCH_SPMV
 }
 void launch_spmv(hipStream_t s, const int32_t* rowptr, const int32_t* col, const double* val, const double* x_ext,
                  const double* scale, double shift, double* y, double* u_out, int64_t n, double* partials, int grid,

@@ -441,8 +441,8 @@ def test_hot_kernels_keep_their_registers():
 
     assert vgprs("8k_updateILb0ELb0E") <= 128      # k_update<real, no inline reduce>
     assert vgprs("6k_dotsILb0ELb1ELb0E") <= 128    # k_dots<real, RED4, single source>
-    assert vgprs("6k_spmvILb0EiE") <= 64           # k_spmv<short rows, int32 row pointers>
-    assert vgprs("6k_spmvILb0ElE") <= 64           # ... int64 row pointers
+    assert vgprs("6k_spmvILb0EiLb0EE") <= 64       # k_spmv<short rows, int32 row pointers, default cache policy>
+    assert vgprs("6k_spmvILb0ElLb0EE") <= 64          # ... int64 row pointers
     assert vgprs("12k_block_spmvE") <= 84          # six waves per SIMD
 
 
